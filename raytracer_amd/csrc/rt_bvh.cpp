@@ -1,0 +1,276 @@
+// rt_bvh.cpp — binned-SAH BVH2 over one mesh, emitted in the "children's boxes in the
+// parent" node layout of rt_layout.h.
+#include "rt_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace rtb {
+namespace {
+
+struct Box {
+  double lo[3], hi[3];
+  void reset() {
+    for (int a = 0; a < 3; a++) {
+      lo[a] = std::numeric_limits<double>::infinity();
+      hi[a] = -std::numeric_limits<double>::infinity();
+    }
+  }
+  void grow(const double* p) {
+    for (int a = 0; a < 3; a++) {
+      lo[a] = std::min(lo[a], p[a]);
+      hi[a] = std::max(hi[a], p[a]);
+    }
+  }
+  void grow(const Box& b) {
+    for (int a = 0; a < 3; a++) {
+      lo[a] = std::min(lo[a], b.lo[a]);
+      hi[a] = std::max(hi[a], b.hi[a]);
+    }
+  }
+  double half_area() const {
+    double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (dx < 0 || dy < 0 || dz < 0) return 0.0;
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+struct TmpNode {
+  Box box;
+  int left = -1, right = -1;  // inner: indices into tmp
+  int first = 0, count = 0;   // leaf range
+};
+
+struct Builder {
+  const double *p1, *p2, *p3;
+  int64_t n;
+  int max_leaf;
+  std::vector<Box> tri_box;
+  std::vector<double> cen;  // 3 per triangle
+  std::vector<uint32_t> idx;
+  std::vector<TmpNode> tmp;
+  int max_depth = 0;
+
+  static constexpr int BINS = 16;
+  static constexpr int DEPTH_LIMIT = 40;  // beyond this, split by median so depth stays bounded
+
+  int build(int first, int count, int depth) {
+    max_depth = std::max(max_depth, depth);
+    TmpNode node;
+    node.box.reset();
+    Box cb;
+    cb.reset();
+    for (int i = 0; i < count; i++) {
+      uint32_t t = idx[first + i];
+      node.box.grow(tri_box[t]);
+      cb.grow(&cen[3 * t]);
+    }
+    node.first = first;
+    node.count = count;
+    int self = (int)tmp.size();
+    tmp.push_back(node);
+    if (count <= 1) return self;
+
+    int best_axis = -1, best_split = -1;
+    double best_cost = std::numeric_limits<double>::infinity();
+    if (depth < DEPTH_LIMIT) {
+      for (int a = 0; a < 3; a++) {
+        double ext = cb.hi[a] - cb.lo[a];
+        if (!(ext > 0.0)) continue;
+        Box bins[BINS];
+        int cnt[BINS];
+        for (int b = 0; b < BINS; b++) {
+          bins[b].reset();
+          cnt[b] = 0;
+        }
+        double k = BINS / ext;
+        for (int i = 0; i < count; i++) {
+          uint32_t t = idx[first + i];
+          int b = (int)((cen[3 * t + a] - cb.lo[a]) * k);
+          b = std::min(std::max(b, 0), BINS - 1);
+          bins[b].grow(tri_box[t]);
+          cnt[b]++;
+        }
+        double right_area[BINS];
+        int right_cnt[BINS];
+        Box acc;
+        acc.reset();
+        int c = 0;
+        for (int b = BINS - 1; b > 0; b--) {
+          acc.grow(bins[b]);
+          c += cnt[b];
+          right_area[b] = acc.half_area();
+          right_cnt[b] = c;
+        }
+        acc.reset();
+        c = 0;
+        for (int b = 0; b < BINS - 1; b++) {
+          acc.grow(bins[b]);
+          c += cnt[b];
+          if (c == 0 || right_cnt[b + 1] == 0) continue;
+          double cost = acc.half_area() * c + right_area[b + 1] * right_cnt[b + 1];
+          if (cost < best_cost) {
+            best_cost = cost;
+            best_axis = a;
+            best_split = b;
+          }
+        }
+      }
+    }
+    // leaf if small enough and splitting does not pay
+    if (count <= max_leaf) {
+      double leaf_cost = node.box.half_area() * count;
+      if (best_axis < 0 || best_cost + node.box.half_area() * 1.0 >= leaf_cost) return self;
+    }
+    int mid;
+    if (best_axis >= 0) {
+      double ext = cb.hi[best_axis] - cb.lo[best_axis];
+      double k = BINS / ext;
+      double lo = cb.lo[best_axis];
+      int axis = best_axis, split = best_split;
+      auto it = std::partition(idx.begin() + first, idx.begin() + first + count, [&](uint32_t t) {
+        int b = (int)((cen[3 * t + axis] - lo) * k);
+        b = std::min(std::max(b, 0), BINS - 1);
+        return b <= split;
+      });
+      mid = (int)(it - (idx.begin() + first));
+    } else {
+      mid = 0;
+    }
+    if (mid <= 0 || mid >= count) {
+      // degenerate (coincident centroids) or depth limit: median split on the widest axis
+      int axis = 0;
+      double ext = -1.0;
+      for (int a = 0; a < 3; a++)
+        if (node.box.hi[a] - node.box.lo[a] > ext) {
+          ext = node.box.hi[a] - node.box.lo[a];
+          axis = a;
+        }
+      mid = count / 2;
+      std::nth_element(idx.begin() + first, idx.begin() + first + mid, idx.begin() + first + count,
+                       [&](uint32_t x, uint32_t y) { return cen[3 * x + axis] < cen[3 * y + axis]; });
+    }
+    int l = build(first, mid, depth + 1);
+    int r = build(first + mid, count - mid, depth + 1);
+    tmp[self].left = l;
+    tmp[self].right = r;
+    return self;
+  }
+};
+
+void set_child(rtd::DNode& N, int which, const Box& b, double pad, int child, int count) {
+  double* lo = which == 0 ? N.lo0 : N.lo1;
+  double* hi = which == 0 ? N.hi0 : N.hi1;
+  for (int a = 0; a < 3; a++) {
+    lo[a] = b.lo[a] - pad;
+    hi[a] = b.hi[a] + pad;
+  }
+  if (which == 0) {
+    N.c0 = child;
+    N.n0 = count;
+  } else {
+    N.c1 = child;
+    N.n1 = count;
+  }
+}
+
+void set_empty(rtd::DNode& N, int which) {
+  double* lo = which == 0 ? N.lo0 : N.lo1;
+  double* hi = which == 0 ? N.hi0 : N.hi1;
+  for (int a = 0; a < 3; a++) {
+    lo[a] = std::numeric_limits<double>::infinity();
+    hi[a] = -std::numeric_limits<double>::infinity();
+  }
+  if (which == 0) {
+    N.c0 = -1;
+    N.n0 = 0;
+  } else {
+    N.c1 = -1;
+    N.n1 = 0;
+  }
+}
+
+}  // namespace
+
+void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, int max_leaf,
+               BuildResult& out) {
+  out.nodes.clear();
+  out.order.clear();
+  out.max_depth = 0;
+  Builder B;
+  B.p1 = p1;
+  B.p2 = p2;
+  B.p3 = p3;
+  B.n = n;
+  B.max_leaf = std::max(1, std::min(max_leaf, 4));
+  B.tri_box.resize(n);
+  B.cen.resize(3 * n);
+  B.idx.resize(n);
+  double scale = 0.0;
+  for (int64_t t = 0; t < n; t++) {
+    Box& b = B.tri_box[t];
+    b.reset();
+    b.grow(p1 + 3 * t);
+    b.grow(p2 + 3 * t);
+    b.grow(p3 + 3 * t);
+    for (int a = 0; a < 3; a++) {
+      B.cen[3 * t + a] = 0.5 * (b.lo[a] + b.hi[a]);
+      scale = std::max(scale, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+    }
+    B.idx[t] = (uint32_t)t;
+  }
+  double pad = scale * BOX_PAD_REL + 1e-300;
+  rtd::DNode zero{};
+  if (n == 0) {
+    rtd::DNode N = zero;
+    set_empty(N, 0);
+    set_empty(N, 1);
+    out.nodes.push_back(N);
+    return;
+  }
+  B.tmp.reserve(2 * n);
+  int root = B.build(0, (int)n, 0);
+  out.max_depth = B.max_depth;
+  out.order = B.idx;
+
+  // Convert: every inner tmp node becomes one DNode carrying its two children's boxes.
+  const TmpNode& R = B.tmp[root];
+  if (R.left < 0) {  // the whole mesh is one leaf
+    rtd::DNode N = zero;
+    set_child(N, 0, R.box, pad, -(R.first + 1), R.count);
+    set_empty(N, 1);
+    out.nodes.push_back(N);
+    return;
+  }
+  // iterative conversion, DFS order (left subtree right after its parent)
+  std::vector<int> map(B.tmp.size(), -1);
+  std::vector<int> stack{root};
+  std::vector<int> order_inner;
+  while (!stack.empty()) {
+    int t = stack.back();
+    stack.pop_back();
+    map[t] = (int)order_inner.size();
+    order_inner.push_back(t);
+    const TmpNode& T = B.tmp[t];
+    if (B.tmp[T.right].left >= 0) stack.push_back(T.right);
+    if (B.tmp[T.left].left >= 0) stack.push_back(T.left);
+  }
+  out.nodes.resize(order_inner.size(), zero);
+  for (size_t i = 0; i < order_inner.size(); i++) {
+    const TmpNode& T = B.tmp[order_inner[i]];
+    rtd::DNode& N = out.nodes[i];
+    const TmpNode& L = B.tmp[T.left];
+    const TmpNode& Rr = B.tmp[T.right];
+    if (L.left >= 0)
+      set_child(N, 0, L.box, pad, map[T.left], 0);
+    else
+      set_child(N, 0, L.box, pad, -(L.first + 1), L.count);
+    if (Rr.left >= 0)
+      set_child(N, 1, Rr.box, pad, map[T.right], 0);
+    else
+      set_child(N, 1, Rr.box, pad, -(Rr.first + 1), Rr.count);
+  }
+}
+
+}  // namespace rtb

@@ -1,0 +1,27 @@
+// rt_bvh.h — host-side BVH construction for one triangle mesh (object space).
+// The hierarchy is a pure culling structure: it decides which triangles a ray tests,
+// never what a test returns.  Boxes are padded so that rounding in the slab test can
+// not drop a triangle the exhaustive loop of the reference (shapes/group.rs:64-71)
+// would have hit.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "rt_layout.h"
+
+namespace rtb {
+
+struct BuildResult {
+  std::vector<rtd::DNode> nodes;  // nodes[0] is the root; child indices are local to this vector
+  std::vector<uint32_t> order;    // order[k] = face index of the k-th triangle record
+  int max_depth = 0;
+};
+
+// p1,p2,p3: n x 3 doubles.  max_leaf: triangles per leaf (<= 4).
+void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, int max_leaf,
+               BuildResult& out);
+
+// Relative padding applied to every box, times the largest |coordinate| of the mesh.
+constexpr double BOX_PAD_REL = 1e-7;
+
+}  // namespace rtb

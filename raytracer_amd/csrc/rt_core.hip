@@ -1,0 +1,684 @@
+// rt_core.hip — the C ABI of include/rt_core.h: scene flattening, commit (BVH build +
+// upload), the render kernels and their launchers.  gfx950 only; there is no CPU path —
+// every entry point that needs the GPU fails with RT_ERR_NO_DEVICE / RT_ERR_HIP without one.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_core.h"
+#include "rt_bvh.h"
+#include "rt_device.h"
+
+using namespace rtd;
+
+// ---------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+  } while (0)
+
+struct MeshH {
+  int32_t group, material;
+  int64_t ntris;
+  uint32_t order_base;
+  std::vector<double> p1, p2, p3, n1, n2, n3;
+  std::vector<uint8_t> smooth;
+  bool has_normals;
+};
+
+struct rt_scene {
+  std::vector<rt_material> mats;
+  std::vector<rt_group> groups;
+  std::vector<rt_primitive> prims;
+  std::vector<uint32_t> prim_order;
+  std::vector<MeshH> meshes;
+  std::vector<DLight> lights;
+  uint32_t next_order = 0;
+  bool committed = false;
+  int device = -1;
+  // device side
+  std::vector<void*> allocs;
+  DScene d{};
+  rt_scene_info info{};
+  unsigned long long* d_counters = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timing_pending = false;
+  uint64_t launches = 0;
+  // scratch for the host-buffer entry point (grow only)
+  double* d_out_f64 = nullptr;
+  uint8_t* d_out_u8 = nullptr;
+  size_t out_cap_px = 0;
+};
+
+static bool affine_rows(const double* m16, double* out12, std::string& why) {
+  if (!(m16[12] == 0.0 && m16[13] == 0.0 && m16[14] == 0.0 && m16[15] == 1.0)) {
+    why = "only affine transforms are supported (last row of the inverse must be 0,0,0,1)";
+    return false;
+  }
+  for (int i = 0; i < 12; i++) {
+    if (!std::isfinite(m16[i])) {
+      why = "non-finite matrix entry";
+      return false;
+    }
+    out12[i] = m16[i];
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// kernels
+
+// Lane -> pixel: the shard's k-th tile is global tile tile_first + k*tile_step; a
+// 64-thread block (one wave) shades one 8x8 pixel patch of it.
+struct PixelMap {
+  int hsize, vsize, tiles_x;
+  int tile_first, tile_step;
+};
+
+__device__ __forceinline__ bool lane_pixel(const PixelMap& pm, int& px, int& py, long long& out_index) {
+  constexpr int PATCHES = (RT_TILE / 8) * (RT_TILE / 8);
+  long long b = blockIdx.x;
+  long long k = b / PATCHES;  // local tile
+  int patch = (int)(b % PATCHES);
+  long long tile = pm.tile_first + k * pm.tile_step;
+  int ty = (int)(tile / pm.tiles_x), tx = (int)(tile % pm.tiles_x);
+  int lane = threadIdx.x;
+  int ix = (patch % (RT_TILE / 8)) * 8 + (lane & 7);
+  int iy = (patch / (RT_TILE / 8)) * 8 + (lane >> 3);
+  px = tx * RT_TILE + ix;
+  py = ty * RT_TILE + iy;
+  if (pm.tile_step == 1)
+    out_index = (long long)py * pm.hsize + px;
+  else
+    out_index = k * (RT_TILE * RT_TILE) + iy * RT_TILE + ix;
+  return px < pm.hsize && py < pm.vsize;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <bool STATS>
+__device__ __forceinline__ void flush_counters(const Counters& c, unsigned long long* g) {
+  if (!STATS) return;
+  const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&c);
+  for (int i = 0; i < N_COUNTERS; i++) {
+    unsigned long long s = wave_sum(src[i]);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&g[i], s);
+  }
+}
+
+// render_thread (camera.rs:165-184): ray_for_pixel + color_at(ray, depth) + write_pixel,
+// one lane per pixel, recursion on a per-lane stack.
+template <bool STATS>
+__global__ void __launch_bounds__(64)
+k_render_mega(DScene S, DCamera cam, PixelMap pm, int depth, double* out_f64, uint8_t* out_u8,
+              unsigned long long* counters) {
+  Counters cnt{};
+  int px, py;
+  long long oi;
+  bool active = lane_pixel(pm, px, py, oi);
+  if (active) {
+    Ray r = ray_for_pixel(cam, px, py);
+    C3 c = color_at<STATS>(S, r, depth, cnt);
+    if (out_f64) {
+      out_f64[oi * 3 + 0] = c.r;
+      out_f64[oi * 3 + 1] = c.g;
+      out_f64[oi * 3 + 2] = c.b;
+    }
+    if (out_u8) {
+      out_u8[oi * 3 + 0] = quantise(c.r);
+      out_u8[oi * 3 + 1] = quantise(c.g);
+      out_u8[oi * 3 + 2] = quantise(c.b);
+    }
+  }
+  flush_counters<STATS>(cnt, counters);
+}
+
+__global__ void k_trace_rays(DScene S, long long n, const double* origins, const double* dirs,
+                             int depth, double* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Counters cnt{};
+  Ray r = {v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
+           v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2])};
+  ShadeOut so{};
+  HitRec h{};
+  bool found = false;
+  C3 c = color_at<false>(S, r, depth, cnt, &so, &h, &found);
+  double* o = out + 32 * i;
+  for (int k = 0; k < 32; k++) o[k] = 0.0;
+  if (!found) return;
+  o[0] = 1.0;
+  o[1] = h.t;
+  o[2] = (double)h.order;
+  o[3] = h.u;
+  o[4] = h.v;
+  o[5] = so.inside ? 1.0 : 0.0;
+  o[6] = so.n1;
+  o[7] = so.n2;
+  const V3* vs[6] = {&so.point, &so.over_point, &so.under_point, &so.eyev, &so.normalv, &so.reflectv};
+  for (int k = 0; k < 6; k++) {
+    o[8 + 3 * k] = vs[k]->x;
+    o[9 + 3 * k] = vs[k]->y;
+    o[10 + 3 * k] = vs[k]->z;
+  }
+  o[26] = so.reflectance;
+  o[27] = c.r;
+  o[28] = c.g;
+  o[29] = c.b;
+  if (S.n_lights > 0) {
+    V3 lpos = v3(S.lights[0].pos[0], S.lights[0].pos[1], S.lights[0].pos[2]);
+    V3 v = vsub(lpos, so.over_point);
+    double distance = vmag(v);
+    Ray sr = {so.over_point, v3(v.x / distance, v.y / distance, v.z / distance)};
+    o[30] = trace_any<false>(S, sr, distance, cnt) ? 1.0 : 0.0;
+  }
+}
+
+// stitch of tile shards into the row-major image (canvas.rs:47-64 for tiles)
+__global__ void k_detile_u8(const uint8_t* tiles, int nshards, long long tiles_per_shard, int hsize,
+                            int vsize, int tiles_x, uint8_t* image) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // pixel index
+  long long npx = (long long)hsize * vsize;
+  if (i >= npx) return;
+  int px = (int)(i % hsize), py = (int)(i / hsize);
+  long long tile = (long long)(py / RT_TILE) * tiles_x + (px / RT_TILE);
+  int shard = (int)(tile % nshards);
+  long long k = tile / nshards;
+  long long src = ((long long)shard * tiles_per_shard + k) * (RT_TILE * RT_TILE) +
+                  (py % RT_TILE) * RT_TILE + (px % RT_TILE);
+  image[3 * i + 0] = tiles[3 * src + 0];
+  image[3 * i + 1] = tiles[3 * src + 1];
+  image[3 * i + 2] = tiles[3 * src + 2];
+}
+
+template <typename T>
+static int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
+  *out = nullptr;
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, bytes));
+  s->allocs.push_back(p);
+  s->info.device_bytes += (int64_t)bytes;
+  if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = static_cast<const T*>(p);
+  return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+
+int rt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+rt_scene* rt_scene_create(void) { return new rt_scene(); }
+
+void rt_scene_destroy(rt_scene* s) {
+  if (!s) return;
+  if (s->committed) {
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(s->device);
+    for (void* p : s->allocs) (void)hipFree(p);
+    if (s->d_out_f64) (void)hipFree(s->d_out_f64);
+    if (s->d_out_u8) (void)hipFree(s->d_out_u8);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    (void)hipSetDevice(cur);
+  }
+  delete s;
+}
+
+int rt_scene_add_material(rt_scene* s, const rt_material* m) {
+  if (!s || !m) return -fail(RT_ERR_ARG, "null argument");
+  if (s->committed) return -fail(RT_ERR_STATE, "scene already committed");
+  if (m->pattern_kind < RT_SOLID || m->pattern_kind > RT_CHECKERED)
+    return -fail(RT_ERR_ARG, "unknown pattern kind");
+  double tmp[12];
+  std::string why;
+  if (!affine_rows(m->pattern_inv, tmp, why)) return -fail(RT_ERR_UNSUPPORTED, "pattern_inv: " + why);
+  s->mats.push_back(*m);
+  return (int)s->mats.size() - 1;
+}
+
+int rt_scene_add_group(rt_scene* s, const rt_group* g) {
+  if (!s || !g) return -fail(RT_ERR_ARG, "null argument");
+  if (s->committed) return -fail(RT_ERR_STATE, "scene already committed");
+  if (g->parent < -1 || g->parent >= (int)s->groups.size())
+    return -fail(RT_ERR_ARG, "group parent out of range");
+  double tmp[12];
+  std::string why;
+  if (!affine_rows(g->inv, tmp, why)) return -fail(RT_ERR_UNSUPPORTED, "group inv: " + why);
+  int depth = 1;
+  for (int p = g->parent; p >= 0; p = s->groups[p].parent) depth++;
+  if (depth > 6) return -fail(RT_ERR_UNSUPPORTED, "groups nested deeper than 6 levels");
+  s->groups.push_back(*g);
+  return (int)s->groups.size() - 1;
+}
+
+int rt_scene_add_primitive(rt_scene* s, const rt_primitive* p) {
+  if (!s || !p) return -fail(RT_ERR_ARG, "null argument");
+  if (s->committed) return -fail(RT_ERR_STATE, "scene already committed");
+  if (p->kind < RT_SPHERE || p->kind > RT_CONE) return -fail(RT_ERR_ARG, "unknown primitive kind");
+  if (p->material < 0 || p->material >= (int)s->mats.size())
+    return -fail(RT_ERR_ARG, "primitive material out of range");
+  if (p->parent < -1 || p->parent >= (int)s->groups.size())
+    return -fail(RT_ERR_ARG, "primitive parent out of range");
+  double tmp[12];
+  std::string why;
+  if (!affine_rows(p->inv, tmp, why)) return -fail(RT_ERR_UNSUPPORTED, "primitive inv: " + why);
+  s->prims.push_back(*p);
+  s->prim_order.push_back(s->next_order++);
+  return (int)s->prims.size() - 1;
+}
+
+int rt_scene_add_mesh(rt_scene* s, const rt_mesh* m) {
+  if (!s || !m) return -fail(RT_ERR_ARG, "null argument");
+  if (s->committed) return -fail(RT_ERR_STATE, "scene already committed");
+  if (m->group < 0 || m->group >= (int)s->groups.size())
+    return -fail(RT_ERR_ARG, "mesh group out of range");
+  if (m->material < 0 || m->material >= (int)s->mats.size())
+    return -fail(RT_ERR_ARG, "mesh material out of range");
+  if (m->ntris < 0 || m->ntris > 0x7fffff00LL) return -fail(RT_ERR_ARG, "bad triangle count");
+  if (m->ntris > 0 && (!m->p1 || !m->p2 || !m->p3)) return -fail(RT_ERR_ARG, "null vertex array");
+  bool has_n = m->n1 || m->n2 || m->n3;
+  if (has_n && !(m->n1 && m->n2 && m->n3))
+    return -fail(RT_ERR_ARG, "n1,n2,n3 must be all given or all NULL");
+  if (m->smooth && !has_n) return -fail(RT_ERR_ARG, "smooth flags without normals");
+  MeshH h;
+  h.group = m->group;
+  h.material = m->material;
+  h.ntris = m->ntris;
+  h.order_base = s->next_order;
+  h.has_normals = has_n;
+  size_t n3 = (size_t)m->ntris * 3;
+  h.p1.assign(m->p1, m->p1 + n3);
+  h.p2.assign(m->p2, m->p2 + n3);
+  h.p3.assign(m->p3, m->p3 + n3);
+  if (has_n) {
+    h.n1.assign(m->n1, m->n1 + n3);
+    h.n2.assign(m->n2, m->n2 + n3);
+    h.n3.assign(m->n3, m->n3 + n3);
+    if (m->smooth)
+      h.smooth.assign(m->smooth, m->smooth + m->ntris);
+    else
+      h.smooth.assign((size_t)m->ntris, 1);
+  } else {
+    h.smooth.assign((size_t)m->ntris, 0);
+  }
+  for (size_t i = 0; i < n3; i++)
+    if (!std::isfinite(h.p1[i]) || !std::isfinite(h.p2[i]) || !std::isfinite(h.p3[i]))
+      return -fail(RT_ERR_ARG, "non-finite vertex");
+  s->next_order += (uint32_t)m->ntris;
+  s->meshes.push_back(std::move(h));
+  return (int)s->meshes.size() - 1;
+}
+
+int rt_scene_add_light(rt_scene* s, const double intensity[3], const double position[3]) {
+  if (!s || !intensity || !position) return -fail(RT_ERR_ARG, "null argument");
+  if (s->committed) return -fail(RT_ERR_STATE, "scene already committed");
+  DLight L;
+  for (int i = 0; i < 3; i++) {
+    L.intensity[i] = intensity[i];
+    L.pos[i] = position[i];
+  }
+  s->lights.push_back(L);
+  return (int)s->lights.size() - 1;
+}
+
+int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
+  if (!s) return fail(RT_ERR_ARG, "null scene");
+  if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
+  if (bvh_builder != 0) return fail(RT_ERR_UNSUPPORTED, "only the host SAH builder (0) is built");
+  int ndev = rt_device_count();
+  if (ndev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible; the render core has no CPU path");
+  if (device < 0) HIP_TRY(hipGetDevice(&device));
+  if (device >= ndev) return fail(RT_ERR_ARG, "device index out of range");
+  auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipSetDevice(device));
+  s->device = device;
+
+  std::string why;
+  std::vector<DGroup> groups(s->groups.size());
+  for (size_t g = 0; g < s->groups.size(); g++) {
+    DGroup& G = groups[g];
+    affine_rows(s->groups[g].inv, G.inv, why);
+    G.parent = s->groups[g].parent;
+    int chain[8], n = 0;
+    for (int p = (int)g; p >= 0; p = s->groups[p].parent) chain[n++] = p;
+    G.nchain = n;
+    for (int k = 0; k < 6; k++) G.chain[k] = 0;
+    for (int k = 0; k < n; k++) G.chain[k] = chain[n - 1 - k];
+  }
+  std::vector<DPrim> prims(s->prims.size());
+  for (size_t p = 0; p < s->prims.size(); p++) {
+    DPrim& P = prims[p];
+    const rt_primitive& src = s->prims[p];
+    affine_rows(src.inv, P.inv, why);
+    P.minimum = src.minimum;
+    P.maximum = src.maximum;
+    P.kind = src.kind;
+    P.material = src.material;
+    P.parent = src.parent;
+    P.closed = src.closed;
+    P.order = s->prim_order[p];
+    P.pad[0] = P.pad[1] = P.pad[2] = 0;
+  }
+  std::vector<DMaterial> mats(s->mats.size());
+  for (size_t m = 0; m < s->mats.size(); m++) {
+    DMaterial& M = mats[m];
+    const rt_material& src = s->mats[m];
+    M.ambient = src.ambient;
+    M.diffuse = src.diffuse;
+    M.specular = src.specular;
+    M.shininess = src.shininess;
+    M.reflective = src.reflective;
+    M.transparency = src.transparency;
+    M.refractive_index = src.refractive_index;
+    for (int i = 0; i < 3; i++) {
+      M.a[i] = src.color_a[i];
+      M.b[i] = src.color_b[i];
+    }
+    affine_rows(src.pattern_inv, M.pinv, why);
+    M.pattern_kind = src.pattern_kind;
+    M.pad[0] = M.pad[1] = M.pad[2] = 0;
+  }
+  // meshes: edges (triangle.rs:49-51), BVH, records in leaf order
+  std::vector<DMesh> meshes(s->meshes.size());
+  std::vector<DTri> tris;
+  std::vector<DTriN> trin;
+  std::vector<DNode> nodes;
+  int64_t total_tris = 0;
+  for (const MeshH& h : s->meshes) total_tris += h.ntris;
+  if (total_tris > 0x7fffff00LL) return fail(RT_ERR_UNSUPPORTED, "too many triangles");
+  tris.reserve((size_t)total_tris);
+  trin.reserve((size_t)total_tris);
+  for (size_t mi = 0; mi < s->meshes.size(); mi++) {
+    const MeshH& h = s->meshes[mi];
+    rtb::BuildResult br;
+    rtb::build_sah(h.p1.data(), h.p2.data(), h.p3.data(), h.ntris, 4, br);
+    if (br.max_depth >= STACK_MAX - 2)
+      return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+    DMesh& M = meshes[mi];
+    M.group = h.group;
+    M.material = h.material;
+    M.order_base = h.order_base;
+    M.root = (int32_t)nodes.size();
+    M.tri_base = (int32_t)tris.size();
+    M.ntris = (int32_t)h.ntris;
+    M.pad[0] = M.pad[1] = 0;
+    int32_t node_base = (int32_t)nodes.size();
+    for (DNode N : br.nodes) {
+      if (N.c0 >= 0) N.c0 += node_base;
+      if (N.c1 >= 0) N.c1 += node_base;
+      nodes.push_back(N);
+    }
+    for (int64_t k = 0; k < h.ntris; k++) {
+      uint32_t f = br.order[k];
+      DTri T;
+      DTriN TN;
+      double e1[3], e2[3];
+      for (int a = 0; a < 3; a++) {
+        T.p1[a] = h.p1[3 * f + a];
+        e1[a] = h.p2[3 * f + a] - h.p1[3 * f + a];
+        e2[a] = h.p3[3 * f + a] - h.p1[3 * f + a];
+        T.e1[a] = e1[a];
+        T.e2[a] = e2[a];
+      }
+      T.orig = f;
+      T.smooth = h.smooth[f];
+      if (T.smooth) {
+        for (int a = 0; a < 3; a++) {
+          TN.n[a] = h.n1[3 * f + a];
+          TN.n[3 + a] = h.n2[3 * f + a];
+          TN.n[6 + a] = h.n3[3 * f + a];
+        }
+      } else {
+        // triangle.rs:51: normalize(cross(e2, e1))
+        double cx = e2[1] * e1[2] - e2[2] * e1[1];
+        double cy = e2[2] * e1[0] - e2[0] * e1[2];
+        double cz = e2[0] * e1[1] - e2[1] * e1[0];
+        double mag = std::sqrt(cx * cx + cy * cy + cz * cz);
+        TN.n[0] = cx / mag;
+        TN.n[1] = cy / mag;
+        TN.n[2] = cz / mag;
+        for (int a = 3; a < 9; a++) TN.n[a] = 0.0;
+      }
+      tris.push_back(T);
+      trin.push_back(TN);
+    }
+  }
+
+  s->info.device_bytes = 0;
+  int rc;
+  if ((rc = upload(s, groups, &s->d.groups))) return rc;
+  if ((rc = upload(s, prims, &s->d.prims))) return rc;
+  if ((rc = upload(s, meshes, &s->d.meshes))) return rc;
+  if ((rc = upload(s, tris, &s->d.tris))) return rc;
+  if ((rc = upload(s, trin, &s->d.trin))) return rc;
+  if ((rc = upload(s, nodes, &s->d.nodes))) return rc;
+  if ((rc = upload(s, mats, &s->d.mats))) return rc;
+  if ((rc = upload(s, s->lights, &s->d.lights))) return rc;
+  s->d.n_groups = (int32_t)groups.size();
+  s->d.n_prims = (int32_t)prims.size();
+  s->d.n_meshes = (int32_t)meshes.size();
+  s->d.n_lights = (int32_t)s->lights.size();
+  void* pc = nullptr;
+  HIP_TRY(hipMalloc(&pc, N_COUNTERS * sizeof(unsigned long long)));
+  s->allocs.push_back(pc);
+  s->d_counters = static_cast<unsigned long long*>(pc);
+  HIP_TRY(hipMemset(pc, 0, N_COUNTERS * sizeof(unsigned long long)));
+  HIP_TRY(hipEventCreate(&s->ev0));
+  HIP_TRY(hipEventCreate(&s->ev1));
+
+  s->info.n_groups = (int64_t)groups.size();
+  s->info.n_primitives = (int64_t)prims.size();
+  s->info.n_meshes = (int64_t)meshes.size();
+  s->info.n_triangles = total_tris;
+  s->info.n_materials = (int64_t)mats.size();
+  s->info.n_lights = (int64_t)s->lights.size();
+  s->info.n_bvh_nodes = (int64_t)nodes.size();
+  s->info.node_bytes = (int32_t)sizeof(DNode);
+  s->info.tri_bytes = (int32_t)sizeof(DTri);
+  s->info.device = device;
+  s->info.bvh_builder = bvh_builder;
+  s->info.commit_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  s->committed = true;
+  return RT_OK;
+}
+
+int rt_scene_get_info(const rt_scene* s, rt_scene_info* info) {
+  if (!s || !info) return fail(RT_ERR_ARG, "null argument");
+  if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+  *info = s->info;
+  return RT_OK;
+}
+
+int64_t rt_shard_tiles(int hsize, int vsize, int tile_first, int tile_step) {
+  if (hsize <= 0 || vsize <= 0 || tile_step <= 0 || tile_first < 0 || tile_first >= tile_step) return -1;
+  int64_t tx = (hsize + RT_TILE - 1) / RT_TILE, ty = (vsize + RT_TILE - 1) / RT_TILE;
+  int64_t total = tx * ty;
+  if (tile_first >= total) return 0;
+  return (total - tile_first + tile_step - 1) / tile_step;
+}
+
+static int camera_to_device(const rt_camera* c, DCamera& d) {
+  if (c->hsize <= 0 || c->vsize <= 0) return fail(RT_ERR_ARG, "camera size must be positive");
+  std::string why;
+  if (!affine_rows(c->inv, d.inv, why)) return fail(RT_ERR_UNSUPPORTED, "camera inv: " + why);
+  d.half_width = c->half_width;
+  d.half_height = c->half_height;
+  d.pixel_size = c->pixel_size;
+  d.hsize = c->hsize;
+  d.vsize = c->vsize;
+  return RT_OK;
+}
+
+int rt_render_device(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline,
+                     int tile_first, int tile_step, double* d_rgb_f64, uint8_t* d_rgb_u8,
+                     void* hip_stream, int want_stats) {
+  if (!s || !cam) return fail(RT_ERR_ARG, "null argument");
+  if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+  if (mode != RT_MODE_F64_PARITY) return fail(RT_ERR_UNSUPPORTED, "only RT_MODE_F64_PARITY is built");
+  if (pipeline != RT_PIPELINE_MEGAKERNEL)
+    return fail(RT_ERR_UNSUPPORTED, "only RT_PIPELINE_MEGAKERNEL is built");
+  if (depth < 0 || depth > MAX_DEPTH) return fail(RT_ERR_ARG, "depth out of range (0..8)");
+  if (!d_rgb_f64 && !d_rgb_u8) return fail(RT_ERR_ARG, "no output buffer");
+  DCamera dc;
+  int rc = camera_to_device(cam, dc);
+  if (rc) return rc;
+  int64_t ntiles = rt_shard_tiles(cam->hsize, cam->vsize, tile_first, tile_step);
+  if (ntiles < 0) return fail(RT_ERR_ARG, "bad tile shard");
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  HIP_TRY(hipSetDevice(s->device));
+  PixelMap pm;
+  pm.hsize = cam->hsize;
+  pm.vsize = cam->vsize;
+  pm.tiles_x = (cam->hsize + RT_TILE - 1) / RT_TILE;
+  pm.tile_first = tile_first;
+  pm.tile_step = tile_step;
+  if (want_stats) HIP_TRY(hipMemsetAsync(s->d_counters, 0, N_COUNTERS * sizeof(unsigned long long), st));
+  HIP_TRY(hipEventRecord(s->ev0, st));
+  s->launches = 0;
+  if (ntiles > 0) {
+    constexpr int PATCHES = (RT_TILE / 8) * (RT_TILE / 8);
+    dim3 grid((unsigned)(ntiles * PATCHES)), block(64);
+    if (want_stats)
+      hipLaunchKernelGGL(k_render_mega<true>, grid, block, 0, st, s->d, dc, pm, depth, d_rgb_f64,
+                         d_rgb_u8, s->d_counters);
+    else
+      hipLaunchKernelGGL(k_render_mega<false>, grid, block, 0, st, s->d, dc, pm, depth, d_rgb_f64,
+                         d_rgb_u8, s->d_counters);
+    HIP_TRY(hipGetLastError());
+    s->launches++;
+  }
+  HIP_TRY(hipEventRecord(s->ev1, st));
+  s->timing_pending = true;
+  return RT_OK;
+}
+
+int rt_render_stats(rt_scene* s, rt_stats* st) {
+  if (!s || !st) return fail(RT_ERR_ARG, "null argument");
+  if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+  HIP_TRY(hipSetDevice(s->device));
+  memset(st, 0, sizeof(*st));
+  if (s->timing_pending) {
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    st->kernel_ms = ms;
+  }
+  unsigned long long c[N_COUNTERS];
+  HIP_TRY(hipMemcpy(c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+  st->rays_primary = c[0];
+  st->rays_shadow = c[1];
+  st->rays_reflect = c[2];
+  st->rays_refract = c[3];
+  st->depth0_skipped = c[4];
+  st->pred_queries = c[5];
+  st->nodes_visited = c[6];
+  st->tri_tests = c[7];
+  st->prim_tests = c[8];
+  st->inst_entries = c[9];
+  st->shade_calls = c[10];
+  st->launches = s->launches;
+  return RT_OK;
+}
+
+int rt_render(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline,
+              double* out_rgb_f64, uint8_t* out_rgb_u8, rt_stats* stats) {
+  if (!s || !cam) return fail(RT_ERR_ARG, "null argument");
+  if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+  if (cam->hsize <= 0 || cam->vsize <= 0) return fail(RT_ERR_ARG, "camera size must be positive");
+  auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipSetDevice(s->device));
+  size_t npx = (size_t)cam->hsize * cam->vsize;
+  if (npx > s->out_cap_px) {
+    if (s->d_out_f64) (void)hipFree(s->d_out_f64);
+    if (s->d_out_u8) (void)hipFree(s->d_out_u8);
+    s->d_out_f64 = nullptr;
+    s->d_out_u8 = nullptr;
+    s->out_cap_px = 0;
+    HIP_TRY(hipMalloc(&s->d_out_f64, npx * 3 * sizeof(double)));
+    HIP_TRY(hipMalloc(&s->d_out_u8, npx * 3));
+    s->out_cap_px = npx;
+  }
+  int rc = rt_render_device(s, cam, depth, mode, pipeline, 0, 1, out_rgb_f64 ? s->d_out_f64 : nullptr,
+                            (out_rgb_u8 || !out_rgb_f64) ? s->d_out_u8 : nullptr, nullptr,
+                            stats ? 1 : 0);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  if (out_rgb_f64)
+    HIP_TRY(hipMemcpy(out_rgb_f64, s->d_out_f64, npx * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  if (out_rgb_u8) HIP_TRY(hipMemcpy(out_rgb_u8, s->d_out_u8, npx * 3, hipMemcpyDeviceToHost));
+  if (stats) {
+    rc = rt_render_stats(s, stats);
+    if (rc) return rc;
+    stats->total_ms =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return RT_OK;
+}
+
+int rt_detile_u8(const uint8_t* d_tiles, int nshards, int64_t tiles_per_shard, int hsize, int vsize,
+                 uint8_t* d_image, void* hip_stream) {
+  if (!d_tiles || !d_image || nshards <= 0 || hsize <= 0 || vsize <= 0 || tiles_per_shard < 0)
+    return fail(RT_ERR_ARG, "bad argument");
+  int tiles_x = (hsize + RT_TILE - 1) / RT_TILE;
+  int64_t total = (int64_t)tiles_x * ((vsize + RT_TILE - 1) / RT_TILE);
+  if ((total + nshards - 1) / nshards > tiles_per_shard)
+    return fail(RT_ERR_ARG, "tiles_per_shard too small for this image");
+  long long npx = (long long)hsize * vsize;
+  dim3 block(256), grid((unsigned)((npx + 255) / 256));
+  hipLaunchKernelGGL(k_detile_u8, grid, block, 0, static_cast<hipStream_t>(hip_stream), d_tiles,
+                     nshards, (long long)tiles_per_shard, hsize, vsize, tiles_x, d_image);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+int rt_trace_rays(rt_scene* s, int64_t n, const double* origins, const double* directions,
+                  int depth, double* out) {
+  if (!s || !origins || !directions || !out || n < 0) return fail(RT_ERR_ARG, "bad argument");
+  if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+  if (depth < 0 || depth > MAX_DEPTH) return fail(RT_ERR_ARG, "depth out of range (0..8)");
+  if (n == 0) return RT_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  double *d_o = nullptr, *d_d = nullptr, *d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_o, n * 3 * sizeof(double)));
+  HIP_TRY(hipMalloc(&d_d, n * 3 * sizeof(double)));
+  HIP_TRY(hipMalloc(&d_out, n * 32 * sizeof(double)));
+  HIP_TRY(hipMemcpy(d_o, origins, n * 3 * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_d, directions, n * 3 * sizeof(double), hipMemcpyHostToDevice));
+  dim3 block(64), grid((unsigned)((n + 63) / 64));
+  hipLaunchKernelGGL(k_trace_rays, grid, block, 0, nullptr, s->d, (long long)n, d_o, d_d, depth, d_out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, n * 32 * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(d_o);
+  (void)hipFree(d_d);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("rt_trace_rays: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1018 @@
+// rt_device.h — device-side scene layout and the per-ray device functions.
+//
+// Everything here is f64 and evaluates each expression in the association the
+// reference uses (citations are file:line under the reference's src/), so that
+// every comparison the reference makes (EPSILON cuts, edge tests, t > 0, shadow
+// distance) sees the same bits.  Build with -ffp-contract=off.
+//
+// What differs from the reference is the search: a ray does not visit every
+// triangle (shapes/group.rs:64-71) but walks a per-mesh box hierarchy that only
+// discards triangles whose padded box the ray misses, and the sorted
+// intersection list (scene/world.rs:22-32) is never materialised — the three
+// consumers of that list are answered by three queries:
+//   hit()                  -> closest positive t, ties by leaf order  (trace_closest)
+//   is_shadowed()          -> any 0 < t < distance                    (trace_any)
+//   refraction containers  -> last "open" shape before the hit        (containers_n1_n2)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_layout.h"
+
+namespace rtd {
+
+constexpr double EPS = 0.00001;  // math/utils.rs:1
+#define RT_INF (__builtin_huge_val())
+
+// ---------------------------------------------------------------------------------------
+struct V3 {
+  double x, y, z;
+};
+struct Ray {
+  V3 o, d;
+};
+struct C3 {
+  double r, g, b;
+};
+
+__device__ __forceinline__ V3 v3(double x, double y, double z) { return {x, y, z}; }
+__device__ __forceinline__ V3 vadd(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 vsub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 vmul(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 vneg(V3 a) { return {a.x * -1.0, a.y * -1.0, a.z * -1.0}; }
+// tuples.rs:153-156: (x*ox + y*oy) + z*oz
+__device__ __forceinline__ double vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// tuples.rs:158-165
+__device__ __forceinline__ V3 vcross(V3 a, V3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// tuples.rs:141-151: sqrt of the sum, then three divisions
+__device__ __forceinline__ double vmag(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ V3 vnormalize(V3 a) {
+  double m = vmag(a);
+  return {a.x / m, a.y / m, a.z / m};
+}
+// tuples.rs:170-174: v - ((n*2.0) * dot(v,n))
+__device__ __forceinline__ V3 vreflect(V3 v, V3 n) {
+  double d = vdot(v, n);
+  V3 n2 = vmul(n, 2.0);
+  return vsub(v, vmul(n2, d));
+}
+__device__ __forceinline__ bool feq(double a, double b) { return fabs(a - b) < EPS; }
+
+// matrix.rs:55-81 for an affine matrix: ((m0*x + m1*y) + m2*z) + m3*w with w = 1 (point)
+__device__ __forceinline__ V3 xf_point(const double* m, V3 p) {
+  return {m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+          m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]};
+}
+// ... and with w = 0 (vector): the last product is a zero and leaves the sum unchanged
+__device__ __forceinline__ V3 xf_vector(const double* m, V3 v) {
+  return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
+          m[8] * v.x + m[9] * v.y + m[10] * v.z};
+}
+// inverse_transform_transpose * normal (intersect.rs:81): rows of the transpose are the
+// columns of inv; the w row/column only feeds the w that the reference zeroes afterwards.
+__device__ __forceinline__ V3 xf_normal(const double* m, V3 n) {
+  return {m[0] * n.x + m[4] * n.y + m[8] * n.z, m[1] * n.x + m[5] * n.y + m[9] * n.z,
+          m[2] * n.x + m[6] * n.y + m[10] * n.z};
+}
+__device__ __forceinline__ Ray xf_ray(const double* m, const Ray& r) {  // ray.rs:32-37
+  return {xf_point(m, r.o), xf_vector(m, r.d)};
+}
+__device__ __forceinline__ V3 ray_at(const Ray& r, double t) {  // ray.rs:16-18
+  return vadd(r.o, vmul(r.d, t));
+}
+
+// Ray into the object space of group g: the reference transforms at every level on the way
+// down (intersect.rs:57-61 at the group, again at each nested group).
+__device__ __forceinline__ Ray ray_to_group(const DScene& S, int g, Ray r) {
+  const DGroup& G = S.groups[g];
+  for (int k = 0; k < G.nchain; k++) r = xf_ray(S.groups[G.chain[k]].inv, r);
+  return r;
+}
+__device__ __forceinline__ V3 point_to_group(const DScene& S, int g, V3 p) {  // intersect.rs:67-77
+  const DGroup& G = S.groups[g];
+  for (int k = 0; k < G.nchain; k++) p = xf_point(S.groups[G.chain[k]].inv, p);
+  return p;
+}
+// intersect.rs:79-92 from the parent upwards: transform, drop w, normalise, per level
+__device__ __forceinline__ V3 normal_up_groups(const DScene& S, int g, V3 n) {
+  while (g >= 0) {
+    const DGroup& G = S.groups[g];
+    n = vnormalize(xf_normal(G.inv, n));
+    g = G.parent;
+  }
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------
+// ttriangle.rs:9-34
+__device__ __forceinline__ bool moller_trumbore(const DTri& T, const Ray& r, double& t, double& u,
+                                                double& v) {
+  V3 e1 = v3(T.e1[0], T.e1[1], T.e1[2]);
+  V3 e2 = v3(T.e2[0], T.e2[1], T.e2[2]);
+  V3 dce2 = vcross(r.d, e2);
+  double det = vdot(e1, dce2);
+  if (fabs(det) < EPS) return false;
+  double f = 1.0 / det;
+  V3 p1o = vsub(r.o, v3(T.p1[0], T.p1[1], T.p1[2]));
+  u = f * vdot(p1o, dce2);
+  if (!(u >= 0.0 && u <= 1.0)) return false;
+  V3 oce1 = vcross(p1o, e1);
+  v = f * vdot(r.d, oce1);
+  if (v < 0.0 || (u + v) > 1.0) return false;
+  t = f * vdot(e2, oce1);
+  return true;
+}
+
+// f64::max / f64::min ignore a NaN operand (cube.rs:74-75, 85-92); so do fmax/fmin.
+__device__ __forceinline__ void cube_axis(double origin, double direction, double& tmin,
+                                          double& tmax) {  // cube.rs:48-66
+  double a = -1.0 - origin;
+  double b = 1.0 - origin;
+  if (fabs(direction) >= EPS) {
+    tmin = a / direction;
+    tmax = b / direction;
+  } else {
+    tmin = a * RT_INF;
+    tmax = b * RT_INF;
+  }
+  if (tmin > tmax) {
+    double s = tmin;
+    tmin = tmax;
+    tmax = s;
+  }
+}
+
+// local_intersect of the closed-form shapes; ts[] in the reference's emission order.
+__device__ inline int prim_local_intersect(const DPrim& P, const Ray& r, double ts[4]) {
+  int n = 0;
+  switch (P.kind) {
+    case 0: {  // sphere.rs:65-84 (origin - point(0,0,0) is the origin itself)
+      V3 str = r.o;
+      double a = vdot(r.d, r.d);
+      double b = 2.0 * vdot(str, r.d);
+      double c = vdot(str, str) - 1.0;
+      double disc = b * b - 4.0 * a * c;
+      if (disc < 0.0) return 0;
+      double sq = sqrt(disc);
+      ts[0] = (-b - sq) / (2.0 * a);
+      ts[1] = (-b + sq) / (2.0 * a);
+      return 2;
+    }
+    case 1: {  // plane.rs:49-58
+      if (fabs(r.d.y) < EPS) return 0;
+      ts[0] = -r.o.y / r.d.y;
+      return 1;
+    }
+    case 2: {  // cube.rs:69-82
+      double x0, x1, y0, y1, z0, z1;
+      cube_axis(r.o.x, r.d.x, x0, x1);
+      cube_axis(r.o.y, r.d.y, y0, y1);
+      cube_axis(r.o.z, r.d.z, z0, z1);
+      double tmin = fmax(fmax(x0, y0), z0);
+      double tmax = fmin(fmin(x1, y1), z1);
+      if (tmin > tmax) return 0;
+      ts[0] = tmin;
+      ts[1] = tmax;
+      return 2;
+    }
+    case 3: {  // cylinder.rs:78-119
+      double a = r.d.x * r.d.x + r.d.z * r.d.z;
+      if (!(fabs(a) < EPS)) {
+        double b = 2.0 * r.o.x * r.d.x + 2.0 * r.o.z * r.d.z;
+        double c = r.o.x * r.o.x + r.o.z * r.o.z - 1.0;
+        double disc = b * b - 4.0 * a * c;
+        if (disc < 0.0) return 0;
+        double sq = sqrt(disc);
+        double t0 = (-b - sq) / (2.0 * a);
+        double t1 = (-b + sq) / (2.0 * a);
+        if (t0 > t1) {
+          double s = t0;
+          t0 = t1;
+          t1 = s;
+        }
+        double y0 = r.o.y + t0 * r.d.y;
+        if (P.minimum < y0 && y0 < P.maximum) ts[n++] = t0;
+        double y1 = r.o.y + t1 * r.d.y;
+        if (P.minimum < y1 && y1 < P.maximum) ts[n++] = t1;
+      }
+      // cylinder.rs:53-74, 166-171
+      if (P.closed && !(fabs(r.d.y) < EPS)) {
+        double t0 = (P.minimum - r.o.y) / r.d.y;
+        double x = r.o.x + t0 * r.d.x, z = r.o.z + t0 * r.d.z;
+        if ((x * x + z * z) <= 1.0) ts[n++] = t0;
+        double t1 = (P.maximum - r.o.y) / r.d.y;
+        x = r.o.x + t1 * r.d.x;
+        z = r.o.z + t1 * r.d.z;
+        if ((x * x + z * z) <= 1.0) ts[n++] = t1;
+      }
+      return n;
+    }
+    case 4: {  // cone.rs:85-122
+      double a = r.d.x * r.d.x - r.d.y * r.d.y + r.d.z * r.d.z;
+      double b = 2.0 * r.d.x * r.o.x - 2.0 * r.d.y * r.o.y + 2.0 * r.d.z * r.o.z;
+      double c = r.o.x * r.o.x - r.o.y * r.o.y + r.o.z * r.o.z;
+      if (fabs(a) <= EPS && fabs(b) > EPS) ts[n++] = -c / (2.0 * b);
+      if (fabs(a) > EPS) {
+        double disc = b * b - 4.0 * a * c;
+        if (disc >= 0.0) {
+          double sq = sqrt(disc);
+          double t0 = (-b - sq) / (2.0 * a);
+          double t1 = (-b + sq) / (2.0 * a);
+          if (t0 > t1) {
+            double s = t0;
+            t0 = t1;
+            t1 = s;
+          }
+          double y0 = r.o.y + t0 * r.d.y;
+          if (P.minimum < y0 && y0 < P.maximum) ts[n++] = t0;
+          double y1 = r.o.y + t1 * r.d.y;
+          if (P.minimum < y1 && y1 < P.maximum) ts[n++] = t1;
+        }
+      }
+      // cone.rs:53-82: caps with radius = the y bound
+      if (P.closed && !(fabs(r.d.y) < EPS)) {
+        double t0 = (P.minimum - r.o.y) / r.d.y;
+        double x = r.o.x + t0 * r.d.x, z = r.o.z + t0 * r.d.z;
+        if ((x * x + z * z) <= P.minimum * P.minimum) ts[n++] = t0;
+        double t1 = (P.maximum - r.o.y) / r.d.y;
+        x = r.o.x + t1 * r.d.x;
+        z = r.o.z + t1 * r.d.z;
+        if ((x * x + z * z) <= P.maximum * P.maximum) ts[n++] = t1;
+      }
+      return n;
+    }
+  }
+  return 0;
+}
+
+__device__ inline V3 prim_local_normal(const DPrim& P, V3 p) {
+  switch (P.kind) {
+    case 0:
+      return p;  // sphere.rs:57-60
+    case 1:
+      return v3(0.0, 1.0, 0.0);  // plane.rs:60-62
+    case 2: {                    // cube.rs:84-101: the component itself, not +-1
+      double ax = fabs(p.x), ay = fabs(p.y), az = fabs(p.z);
+      double maxc = fmax(fmax(ax, ay), az);
+      if (maxc == ax) return v3(p.x, 0.0, 0.0);
+      if (maxc == ay) return v3(0.0, p.y, 0.0);
+      return v3(0.0, 0.0, p.z);
+    }
+    case 3: {  // cylinder.rs:121-131
+      double dist = p.x * p.x + p.z * p.z;
+      if (dist < 1.0 && p.y >= P.maximum - EPS) return v3(0.0, 1.0, 0.0);
+      if (dist < 1.0 && p.y <= P.minimum + EPS) return v3(0.0, -1.0, 0.0);
+      return v3(p.x, 0.0, p.z);
+    }
+    default: {  // cone.rs:124-138 (keeps the reference's `dist < 1.0` cap test)
+      double dist = p.x * p.x + p.z * p.z;
+      if (dist < 1.0 && p.y >= P.maximum - EPS) return v3(0.0, 1.0, 0.0);
+      if (dist < 1.0 && p.y <= P.minimum + EPS) return v3(0.0, -1.0, 0.0);
+      double y = sqrt(dist);
+      if (p.y > 0.0) y *= -1.0;
+      return v3(p.x, y, p.z);
+    }
+  }
+}
+
+__device__ __forceinline__ Ray ray_to_prim(const DScene& S, const DPrim& P, const Ray& r) {
+  Ray q = r;
+  if (P.parent >= 0) q = ray_to_group(S, P.parent, q);
+  return xf_ray(P.inv, q);
+}
+
+// ---------------------------------------------------------------------------------------
+// Ray / padded-box slab test.  Returns the parametric interval of the infinite line.
+// Boxes are padded at build time, so the few-ulp error of (lo-o)*inv never drops a
+// triangle; min/max ignore the NaN of 0*inf (origin exactly on a slab plane of a
+// direction-parallel axis), which then yields an empty interval for a ray that is a
+// whole pad width away from the geometry.
+__device__ __forceinline__ void slab(const double lo[3], const double hi[3], V3 o, V3 inv,
+                                     double& tn, double& tf) {
+  double ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
+  double ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
+  double az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+  tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+  tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+}
+
+struct HitRec {
+  double t, u, v;
+  uint32_t order;
+  int32_t prim;  // >= 0: primitive index; -1: triangle
+  int32_t mesh;
+  int32_t tri;  // global record index in the triangle table
+};
+
+constexpr int STACK_MAX = 64;
+
+// hit() of intersect.rs:125-139 over the list of world.rs:22-32: smallest t > 0, the
+// earliest leaf among equal t.
+template <bool STATS>
+__device__ inline bool trace_closest(const DScene& S, const Ray& ray, HitRec& h, Counters& cnt) {
+  double best_t = RT_INF;
+  uint32_t best_order = 0xffffffffu;
+  h.prim = -1;
+  h.mesh = -1;
+  h.tri = -1;
+  h.u = 0.0;
+  h.v = 0.0;
+  bool found = false;
+  for (int p = 0; p < S.n_prims; p++) {
+    const DPrim& P = S.prims[p];
+    Ray lr = ray_to_prim(S, P, ray);
+    double ts[4];
+    int n = prim_local_intersect(P, lr, ts);
+    if (STATS) cnt.prim_tests++;
+    for (int k = 0; k < n; k++) {
+      double t = ts[k];
+      if (t > 0.0 && (t < best_t || (t == best_t && P.order < best_order))) {
+        best_t = t;
+        best_order = P.order;
+        h.prim = p;
+        found = true;
+      }
+    }
+  }
+  int stack[STACK_MAX];
+  for (int m = 0; m < S.n_meshes; m++) {
+    const DMesh& M = S.meshes[m];
+    Ray lr = ray_to_group(S, M.group, ray);
+    if (STATS) cnt.inst_entries++;
+    V3 inv = v3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
+    const DTri* tris = S.tris + M.tri_base;
+    int sp = 0;
+    int node = M.root;
+    while (true) {
+      const DNode& N = S.nodes[node];
+      if (STATS) cnt.nodes_visited++;
+      double tn0, tf0, tn1, tf1;
+      slab(N.lo0, N.hi0, lr.o, inv, tn0, tf0);
+      slab(N.lo1, N.hi1, lr.o, inv, tn1, tf1);
+      bool h0 = (tn0 <= tf0) && (tf0 >= 0.0) && (tn0 <= best_t) && (N.n0 != 0 || N.c0 >= 0);
+      bool h1 = (tn1 <= tf1) && (tf1 >= 0.0) && (tn1 <= best_t) && (N.n1 != 0 || N.c1 >= 0);
+      int next0 = -1, next1 = -1;
+      if (h0) {
+        if (N.c0 >= 0) {
+          next0 = N.c0;
+        } else {
+          int first = -(N.c0 + 1);
+          for (int k = 0; k < N.n0; k++) {
+            const DTri& T = tris[first + k];
+            double t, u, v;
+            if (STATS) cnt.tri_tests++;
+            if (moller_trumbore(T, lr, t, u, v)) {
+              uint32_t ord = M.order_base + T.orig;
+              if (t > 0.0 && (t < best_t || (t == best_t && ord < best_order))) {
+                best_t = t;
+                best_order = ord;
+                h.prim = -1;
+                h.mesh = m;
+                h.tri = M.tri_base + first + k;
+                h.u = u;
+                h.v = v;
+                found = true;
+              }
+            }
+          }
+        }
+      }
+      if (h1) {
+        if (N.c1 >= 0) {
+          next1 = N.c1;
+        } else {
+          int first = -(N.c1 + 1);
+          for (int k = 0; k < N.n1; k++) {
+            const DTri& T = tris[first + k];
+            double t, u, v;
+            if (STATS) cnt.tri_tests++;
+            if (moller_trumbore(T, lr, t, u, v)) {
+              uint32_t ord = M.order_base + T.orig;
+              if (t > 0.0 && (t < best_t || (t == best_t && ord < best_order))) {
+                best_t = t;
+                best_order = ord;
+                h.prim = -1;
+                h.mesh = m;
+                h.tri = M.tri_base + first + k;
+                h.u = u;
+                h.v = v;
+                found = true;
+              }
+            }
+          }
+        }
+      }
+      if (next0 >= 0 && next1 >= 0) {
+        // nearer child first; the other waits on the stack
+        if (tn1 < tn0) {
+          int s = next0;
+          next0 = next1;
+          next1 = s;
+        }
+        if (sp < STACK_MAX) stack[sp++] = next1;
+        node = next0;
+      } else if (next0 >= 0) {
+        node = next0;
+      } else if (next1 >= 0) {
+        node = next1;
+      } else {
+        if (sp == 0) break;
+        node = stack[--sp];
+      }
+    }
+  }
+  h.t = best_t;
+  h.order = best_order;
+  return found;
+}
+
+// is_shadowed (world.rs:116-134): the nearest positive hit is closer than `distance`
+// exactly when some intersection has 0 < t < distance.
+template <bool STATS>
+__device__ inline bool trace_any(const DScene& S, const Ray& ray, double distance, Counters& cnt) {
+  for (int p = 0; p < S.n_prims; p++) {
+    const DPrim& P = S.prims[p];
+    Ray lr = ray_to_prim(S, P, ray);
+    double ts[4];
+    int n = prim_local_intersect(P, lr, ts);
+    if (STATS) cnt.prim_tests++;
+    for (int k = 0; k < n; k++)
+      if (ts[k] > 0.0 && ts[k] < distance) return true;
+  }
+  int stack[STACK_MAX];
+  for (int m = 0; m < S.n_meshes; m++) {
+    const DMesh& M = S.meshes[m];
+    Ray lr = ray_to_group(S, M.group, ray);
+    if (STATS) cnt.inst_entries++;
+    V3 inv = v3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
+    const DTri* tris = S.tris + M.tri_base;
+    int sp = 0;
+    int node = M.root;
+    while (true) {
+      const DNode& N = S.nodes[node];
+      if (STATS) cnt.nodes_visited++;
+      double tn0, tf0, tn1, tf1;
+      slab(N.lo0, N.hi0, lr.o, inv, tn0, tf0);
+      slab(N.lo1, N.hi1, lr.o, inv, tn1, tf1);
+      bool h0 = (tn0 <= tf0) && (tf0 >= 0.0) && (tn0 <= distance) && (N.n0 != 0 || N.c0 >= 0);
+      bool h1 = (tn1 <= tf1) && (tf1 >= 0.0) && (tn1 <= distance) && (N.n1 != 0 || N.c1 >= 0);
+      int next0 = -1, next1 = -1;
+      if (h0) {
+        if (N.c0 >= 0) {
+          next0 = N.c0;
+        } else {
+          int first = -(N.c0 + 1);
+          for (int k = 0; k < N.n0; k++) {
+            double t, u, v;
+            if (STATS) cnt.tri_tests++;
+            if (moller_trumbore(tris[first + k], lr, t, u, v) && t > 0.0 && t < distance)
+              return true;
+          }
+        }
+      }
+      if (h1) {
+        if (N.c1 >= 0) {
+          next1 = N.c1;
+        } else {
+          int first = -(N.c1 + 1);
+          for (int k = 0; k < N.n1; k++) {
+            double t, u, v;
+            if (STATS) cnt.tri_tests++;
+            if (moller_trumbore(tris[first + k], lr, t, u, v) && t > 0.0 && t < distance)
+              return true;
+          }
+        }
+      }
+      if (next0 >= 0 && next1 >= 0) {
+        if (sp < STACK_MAX) stack[sp++] = next1;
+        node = next0;
+      } else if (next0 >= 0) {
+        node = next0;
+      } else if (next1 >= 0) {
+        node = next1;
+      } else {
+        if (sp == 0) break;
+        node = stack[--sp];
+      }
+    }
+  }
+  return false;
+}
+
+// Sort key of one entry of the reference's intersection list: ascending t, ties by leaf
+// order, then by emission order inside one shape (stable sorts, group.rs:69, world.rs:29).
+struct Key {
+  double t;
+  uint32_t order;
+  int32_t emit;
+};
+__device__ __forceinline__ bool key_less(const Key& a, const Key& b) {
+  if (a.t < b.t) return true;
+  if (a.t > b.t) return false;
+  if (a.order != b.order) return a.order < b.order;
+  return a.emit < b.emit;
+}
+
+// Largest key below K among all triangle intersections of the infinite line (t may be
+// negative).  Every triangle is its own shape with at most one entry, so this is the last
+// triangle still "open" when the containers walk of intersect.rs:188-222 reaches K.
+template <bool STATS>
+__device__ inline bool tri_predecessor(const DScene& S, const Ray& ray, const Key& K, Key& best,
+                                       int& best_mesh, Counters& cnt) {
+  bool found = false;
+  int stack[STACK_MAX];
+  for (int m = 0; m < S.n_meshes; m++) {
+    const DMesh& M = S.meshes[m];
+    Ray lr = ray_to_group(S, M.group, ray);
+    if (STATS) cnt.inst_entries++;
+    V3 inv = v3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
+    const DTri* tris = S.tris + M.tri_base;
+    int sp = 0;
+    int node = M.root;
+    while (true) {
+      const DNode& N = S.nodes[node];
+      if (STATS) cnt.nodes_visited++;
+      double tn0, tf0, tn1, tf1;
+      slab(N.lo0, N.hi0, lr.o, inv, tn0, tf0);
+      slab(N.lo1, N.hi1, lr.o, inv, tn1, tf1);
+      double floor_t = found ? best.t : -RT_INF;
+      bool h0 = (tn0 <= tf0) && (tn0 <= K.t) && (tf0 >= floor_t) && (N.n0 != 0 || N.c0 >= 0);
+      bool h1 = (tn1 <= tf1) && (tn1 <= K.t) && (tf1 >= floor_t) && (N.n1 != 0 || N.c1 >= 0);
+      int next0 = -1, next1 = -1;
+      if (h0) {
+        if (N.c0 >= 0) {
+          next0 = N.c0;
+        } else {
+          int first = -(N.c0 + 1);
+          for (int k = 0; k < N.n0; k++) {
+            const DTri& T = tris[first + k];
+            double t, u, v;
+            if (STATS) cnt.tri_tests++;
+            if (moller_trumbore(T, lr, t, u, v)) {
+              Key c{t, M.order_base + T.orig, 0};
+              if (key_less(c, K) && (!found || key_less(best, c))) {
+                best = c;
+                best_mesh = m;
+                found = true;
+              }
+            }
+          }
+        }
+      }
+      if (h1) {
+        if (N.c1 >= 0) {
+          next1 = N.c1;
+        } else {
+          int first = -(N.c1 + 1);
+          for (int k = 0; k < N.n1; k++) {
+            const DTri& T = tris[first + k];
+            double t, u, v;
+            if (STATS) cnt.tri_tests++;
+            if (moller_trumbore(T, lr, t, u, v)) {
+              Key c{t, M.order_base + T.orig, 0};
+              if (key_less(c, K) && (!found || key_less(best, c))) {
+                best = c;
+                best_mesh = m;
+                found = true;
+              }
+            }
+          }
+        }
+      }
+      if (next0 >= 0 && next1 >= 0) {
+        // the child reaching further towards K first
+        if (tf1 > tf0) {
+          int s = next0;
+          next0 = next1;
+          next1 = s;
+        }
+        if (sp < STACK_MAX) stack[sp++] = next1;
+        node = next0;
+      } else if (next0 >= 0) {
+        node = next0;
+      } else if (next1 >= 0) {
+        node = next1;
+      } else {
+        if (sp == 0) break;
+        node = stack[--sp];
+      }
+    }
+  }
+  return found;
+}
+
+// n1/n2 of prepare_computations (intersect.rs:188-222) without the list.
+// The walk toggles a shape in `containers` at each of its entries, and reads
+// containers.last() just before and just after toggling the hit's shape at the first
+// entry of that shape within EPSILON of the hit's t (hits_equal, intersect.rs:164-166).
+// A shape is in the list when it has an odd number of entries before that point, and the
+// list is ordered by each shape's latest entry; so last() is the odd-count shape whose
+// latest entry has the largest key.
+template <bool STATS>
+__device__ inline void containers_n1_n2(const DScene& S, const Ray& ray, const HitRec& h,
+                                        double own_ri, double& n1, double& n2, Counters& cnt) {
+  if (STATS) cnt.pred_queries++;
+  Key K{h.t, h.order, 0};
+  if (h.prim >= 0) {
+    const DPrim& P = S.prims[h.prim];
+    Ray lr = ray_to_prim(S, P, ray);
+    double ts[4];
+    int n = prim_local_intersect(P, lr, ts);
+    bool have = false;
+    for (int k = 0; k < n; k++) {
+      if (!feq(ts[k], h.t)) continue;
+      Key c{ts[k], P.order, k};
+      if (!have || key_less(c, K)) {
+        K = c;
+        have = true;
+      }
+    }
+  }
+  bool have_all = false, have_others = false, own_odd = false;
+  Key best_all{0.0, 0u, 0}, best_others{0.0, 0u, 0};
+  double ri_all = 1.0, ri_others = 1.0;
+  for (int p = 0; p < S.n_prims; p++) {
+    const DPrim& P = S.prims[p];
+    Ray lr = ray_to_prim(S, P, ray);
+    double ts[4];
+    int n = prim_local_intersect(P, lr, ts);
+    if (STATS) cnt.prim_tests++;
+    int count = 0;
+    bool have = false;
+    Key last{0.0, 0u, 0};
+    for (int k = 0; k < n; k++) {
+      Key c{ts[k], P.order, k};
+      if (!key_less(c, K)) continue;
+      count++;
+      if (!have || key_less(last, c)) {
+        last = c;
+        have = true;
+      }
+    }
+    if ((count & 1) == 0) continue;
+    double ri = S.mats[P.material].refractive_index;
+    if (!have_all || key_less(best_all, last)) {
+      best_all = last;
+      ri_all = ri;
+      have_all = true;
+    }
+    if (p == h.prim) {
+      own_odd = true;
+    } else if (!have_others || key_less(best_others, last)) {
+      best_others = last;
+      ri_others = ri;
+      have_others = true;
+    }
+  }
+  if (S.n_meshes > 0) {
+    Key tb{0.0, 0u, 0};
+    int tm = -1;
+    if (tri_predecessor<STATS>(S, ray, K, tb, tm, cnt)) {
+      double ri = S.mats[S.meshes[tm].material].refractive_index;
+      if (!have_all || key_less(best_all, tb)) {
+        best_all = tb;
+        ri_all = ri;
+        have_all = true;
+      }
+      if (!have_others || key_less(best_others, tb)) {
+        best_others = tb;
+        ri_others = ri;
+        have_others = true;
+      }
+    }
+  }
+  n1 = have_all ? ri_all : 1.0;
+  if (own_odd)
+    n2 = have_others ? ri_others : 1.0;  // the hit leaves its own shape
+  else
+    n2 = own_ri;  // the hit enters its own shape, which becomes the last container
+}
+
+// ---------------------------------------------------------------------------------------
+// Rust `x as i64`: saturating, NaN -> 0.  Only the parity is used.
+__device__ __forceinline__ bool floor_is_even(double f) {
+  if (f != f) return true;                       // NaN -> 0
+  if (f >= 9223372036854775807.0) return false;  // i64::MAX is odd
+  if (f <= -9223372036854775808.0) return true;  // i64::MIN is even
+  long long i = (long long)f;
+  return (i % 2) == 0;
+}
+__device__ inline C3 pattern_color(const DMaterial& M, V3 p) {  // patterns.rs
+  C3 a = {M.a[0], M.a[1], M.a[2]};
+  C3 b = {M.b[0], M.b[1], M.b[2]};
+  switch (M.pattern_kind) {
+    case 1:
+      return floor_is_even(floor(p.x)) ? a : b;  // patterns.rs:77-83
+    case 2: {                                    // patterns.rs:145-149
+      double fr = p.x - floor(p.x);
+      return {a.r + (b.r - a.r) * fr, a.g + (b.g - a.g) * fr, a.b + (b.b - a.b) * fr};
+    }
+    case 3:
+      return floor_is_even(floor(sqrt(p.x * p.x + p.z * p.z))) ? a : b;  // patterns.rs:223-229
+    case 4:
+      return floor_is_even(floor(p.x) + floor(p.y) + floor(p.z)) ? a : b;  // patterns.rs:277-283
+    default:
+      return a;  // patterns.rs:30-32
+  }
+}
+
+// Result of shading one hit (shade_hit, world.rs:34-65, up to the two recursive calls).
+struct ShadeOut {
+  C3 surface;
+  double reflective, transparency, reflectance;
+  bool use_schlick;  // reflective > 0 && transparency > 0
+  bool do_reflect;   // !f64_eq(reflective, 0)
+  bool do_refract;   // !f64_eq(transparency, 0) and no total internal reflection
+  Ray reflect_ray, refract_ray;
+  // for the known-answer interface
+  V3 point, over_point, under_point, eyev, normalv, reflectv;
+  double n1, n2;
+  bool inside;
+};
+
+// prepare_computations (intersect.rs:168-237) + the light loop of shade_hit + the ray
+// set-up of reflected_color / refracted_color / schlick (world.rs:78-165).
+template <bool STATS>
+__device__ inline void shade_hit_local(const DScene& S, const Ray& ray, const HitRec& h,
+                                       ShadeOut& o, Counters& cnt) {
+  if (STATS) cnt.shade_calls++;
+  V3 point = ray_at(ray, h.t);
+  V3 normal;
+  int mat_index;
+  int parent_group;
+  const double* leaf_inv = nullptr;
+  if (h.prim >= 0) {
+    const DPrim& P = S.prims[h.prim];
+    mat_index = P.material;
+    parent_group = P.parent;
+    leaf_inv = P.inv;
+    V3 lp = point;
+    if (P.parent >= 0) lp = point_to_group(S, P.parent, lp);
+    lp = xf_point(P.inv, lp);
+    V3 ln = prim_local_normal(P, lp);
+    normal = vnormalize(xf_normal(P.inv, ln));  // intersect.rs:81-83
+  } else {
+    const DMesh& M = S.meshes[h.mesh];
+    const DTri& T = S.tris[h.tri];
+    const DTriN& TN = S.trin[h.tri];
+    mat_index = M.material;
+    parent_group = M.group;
+    V3 ln;
+    if (T.smooth) {  // smooth_triangle.rs:114-118: (n2*u + n3*v) + n1*((1-u)-v)
+      double w = 1.0 - h.u - h.v;
+      ln = v3(TN.n[3] * h.u + TN.n[6] * h.v + TN.n[0] * w,
+              TN.n[4] * h.u + TN.n[7] * h.v + TN.n[1] * w,
+              TN.n[5] * h.u + TN.n[8] * h.v + TN.n[2] * w);
+    } else {
+      ln = v3(TN.n[0], TN.n[1], TN.n[2]);  // triangle.rs:95-97
+    }
+    normal = vnormalize(ln);  // the triangle's own (identity) level of intersect.rs:79-92
+  }
+  normal = normal_up_groups(S, parent_group, normal);
+
+  const DMaterial& M = S.mats[mat_index];
+  V3 eyev = vneg(ray.d);
+  bool inside = vdot(normal, eyev) < 0.0;
+  if (inside) normal = vmul(normal, -1.0);
+  V3 over = vadd(point, vmul(normal, EPS));
+  V3 under = vsub(point, vmul(normal, EPS));
+  V3 reflectv = vreflect(ray.d, normal);
+  o.point = point;
+  o.over_point = over;
+  o.under_point = under;
+  o.eyev = eyev;
+  o.normalv = normal;
+  o.reflectv = reflectv;
+  o.inside = inside;
+
+  // light loop, world.rs:43-52 with lighting() of light.rs:23-85
+  C3 surface = {0.0, 0.0, 0.0};
+  C3 pc = {M.a[0], M.a[1], M.a[2]};
+  if (M.pattern_kind != 0) {
+    V3 op = over;  // world.rs:50: world_to_object(over_point)
+    if (parent_group >= 0) op = point_to_group(S, parent_group, op);
+    if (leaf_inv) op = xf_point(leaf_inv, op);
+    pc = pattern_color(M, xf_point(M.pinv, op));
+  }
+  for (int li = 0; li < S.n_lights; li++) {
+    const DLight& L = S.lights[li];
+    V3 lpos = v3(L.pos[0], L.pos[1], L.pos[2]);
+    // is_shadowed, world.rs:116-134
+    V3 v = vsub(lpos, over);
+    double distance = vmag(v);
+    V3 direction = v3(v.x / distance, v.y / distance, v.z / distance);
+    Ray sr = {over, direction};
+    if (STATS) cnt.rays_shadow++;
+    bool shadow = trace_any<STATS>(S, sr, distance, cnt);
+    // lighting
+    C3 eff = {pc.r * L.intensity[0], pc.g * L.intensity[1], pc.b * L.intensity[2]};
+    V3 lightv = direction;  // normalize(light.position - position): the same expression
+    C3 ambient = {eff.r * M.ambient, eff.g * M.ambient, eff.b * M.ambient};
+    double ldn = vdot(lightv, normal);
+    C3 diffuse = {0.0, 0.0, 0.0}, specular = {0.0, 0.0, 0.0};
+    if (!(shadow || ldn < 0.0)) {
+      diffuse = {eff.r * M.diffuse * ldn, eff.g * M.diffuse * ldn, eff.b * M.diffuse * ldn};
+      V3 rv = vreflect(vneg(lightv), normal);
+      double rde = vdot(rv, eyev);
+      if (!(rde <= 0.0)) {
+        double factor = pow(rde, M.shininess);
+        specular = {L.intensity[0] * M.specular * factor, L.intensity[1] * M.specular * factor,
+                    L.intensity[2] * M.specular * factor};
+      }
+    }
+    surface.r += ambient.r + diffuse.r + specular.r;
+    surface.g += ambient.g + diffuse.g + specular.g;
+    surface.b += ambient.b + diffuse.b + specular.b;
+  }
+  o.surface = surface;
+  o.reflective = M.reflective;
+  o.transparency = M.transparency;
+  o.do_reflect = !feq(M.reflective, 0.0);  // world.rs:79
+  o.reflect_ray = {over, reflectv};
+  o.use_schlick = (M.reflective > 0.) && (M.transparency > 0.);  // world.rs:57-59
+  o.do_refract = false;
+  o.reflectance = 0.0;
+  o.n1 = 1.0;
+  o.n2 = 1.0;
+  bool want_refract = !feq(M.transparency, 0.0);  // world.rs:90
+  if (want_refract || o.use_schlick) {
+    double n1, n2;
+    containers_n1_n2<STATS>(S, ray, h, M.refractive_index, n1, n2, cnt);
+    o.n1 = n1;
+    o.n2 = n2;
+    if (want_refract) {  // world.rs:94-112
+      double n_ratio = n1 / n2;
+      double cos_i = vdot(eyev, normal);
+      double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+      if (!(sin2_t > 1.)) {
+        double cos_t = sqrt(1. - sin2_t);
+        V3 dir = vsub(vmul(normal, n_ratio * cos_i - cos_t), vmul(eyev, n_ratio));
+        o.refract_ray = {under, dir};
+        o.do_refract = true;
+      }
+    }
+    if (o.use_schlick) {  // world.rs:151-165
+      double c = vdot(eyev, normal);
+      bool total = false;
+      if (n1 > n2) {
+        double n = n1 / n2;
+        double sin2_t = n * n * (1. - c * c);
+        if (sin2_t > 1.)
+          total = true;
+        else
+          c = sqrt(1. - sin2_t);
+      }
+      if (total) {
+        o.reflectance = 1.;
+      } else {
+        double q = (n1 - n2) / (n1 + n2);
+        double r0 = q * q;
+        double x = 1. - c;
+        double x2 = x * x;
+        double x5 = x * (x2 * x2);  // powi(5) by repeated squaring
+        o.reflectance = r0 + (1. - r0) * x5;
+      }
+    }
+  }
+}
+
+// world.rs:57-64
+__device__ __forceinline__ C3 combine(const C3& surface, const C3& reflected, const C3& refracted,
+                                      bool use_schlick, double reflectance) {
+  if (use_schlick) {
+    double k = 1. - reflectance;
+    return {surface.r + reflected.r * reflectance + refracted.r * k,
+            surface.g + reflected.g * reflectance + refracted.g * k,
+            surface.b + reflected.b * reflectance + refracted.b * k};
+  }
+  return {surface.r + reflected.r + refracted.r, surface.g + reflected.g + refracted.g,
+          surface.b + reflected.b + refracted.b};
+}
+
+// One saved level of the color_at recursion (world.rs:67-114).
+struct Frame {
+  C3 surface, reflected;
+  double reflective, transparency, reflectance;
+  Ray refract_ray;
+  uint8_t use_schlick, do_refract, state;  // state 1: waiting for the reflected child, 2: refracted
+};
+
+constexpr int MAX_DEPTH = 8;
+
+// World::color_at(ray, depth) with the recursion unrolled onto an explicit stack.
+template <bool STATS>
+__device__ inline C3 color_at(const DScene& S, Ray ray, int depth, Counters& cnt,
+                              ShadeOut* first_out = nullptr, HitRec* first_hit = nullptr,
+                              bool* first_found = nullptr) {
+  Frame frames[MAX_DEPTH];
+  int level = 0;
+  C3 ret = {0.0, 0.0, 0.0};
+  if (depth > MAX_DEPTH) depth = MAX_DEPTH;
+  int remaining = depth;  // depth argument of the current color_at call
+  if (STATS) cnt.rays_primary++;
+  while (true) {
+    // ---- enter color_at(ray, remaining), remaining >= 1 or the top-level call
+    HitRec h;
+    bool found = trace_closest<STATS>(S, ray, h, cnt);
+    if (level == 0 && first_found) *first_found = found;
+    bool returning = true;
+    if (found && (remaining > 0 || (level == 0 && first_out))) {
+      ShadeOut so;
+      shade_hit_local<STATS>(S, ray, h, so, cnt);
+      if (level == 0 && first_out) {
+        *first_out = so;
+        *first_hit = h;
+      }
+      if (remaining > 0) {
+        Frame& F = frames[level];
+        F.surface = so.surface;
+        F.reflected = {0.0, 0.0, 0.0};
+        F.reflective = so.reflective;
+        F.transparency = so.transparency;
+        F.reflectance = so.reflectance;
+        F.use_schlick = so.use_schlick;
+        F.do_refract = so.do_refract;
+        F.refract_ray = so.refract_ray;
+        int child = remaining - 1;
+        if (so.do_reflect && child > 0) {
+          F.state = 1;
+          ray = so.reflect_ray;
+          level++;
+          remaining = child;
+          if (STATS) cnt.rays_reflect++;
+          continue;
+        }
+        if (so.do_reflect && STATS) cnt.depth0_skipped++;
+        if (so.do_refract && child > 0) {
+          F.state = 2;
+          ray = so.refract_ray;
+          level++;
+          remaining = child;
+          if (STATS) cnt.rays_refract++;
+          continue;
+        }
+        if (so.do_refract && STATS) cnt.depth0_skipped++;
+        C3 zero = {0.0, 0.0, 0.0};
+        ret = combine(F.surface, zero, zero, F.use_schlick, F.reflectance);
+      } else {
+        ret = {0.0, 0.0, 0.0};
+      }
+    } else {
+      ret = {0.0, 0.0, 0.0};  // world.rs:74 (no hit) or world.rs:37-39 (depth 0)
+    }
+    // ---- return `ret` to the callers
+    while (returning) {
+      if (level == 0) return ret;
+      level--;
+      remaining++;
+      Frame& F = frames[level];
+      if (F.state == 1) {
+        // reflected_color: color * reflective (world.rs:85)
+        F.reflected = {ret.r * F.reflective, ret.g * F.reflective, ret.b * F.reflective};
+        int child = remaining - 1;
+        if (F.do_refract && child > 0) {
+          F.state = 2;
+          ray = F.refract_ray;
+          level++;
+          remaining = child;
+          if (STATS) cnt.rays_refract++;
+          returning = false;
+          break;
+        }
+        if (F.do_refract && STATS) cnt.depth0_skipped++;
+        C3 zero = {0.0, 0.0, 0.0};
+        ret = combine(F.surface, F.reflected, zero, F.use_schlick, F.reflectance);
+      } else {
+        // refracted_color: color * transparency (world.rs:112)
+        C3 refracted = {ret.r * F.transparency, ret.g * F.transparency, ret.b * F.transparency};
+        ret = combine(F.surface, F.reflected, refracted, F.use_schlick, F.reflectance);
+      }
+    }
+  }
+}
+
+// camera.rs:64-80 with the inverse precomputed
+__device__ __forceinline__ Ray ray_for_pixel(const DCamera& cam, int px, int py) {
+  double x_offset = ((double)px + 0.5) * cam.pixel_size;
+  double y_offset = ((double)py + 0.5) * cam.pixel_size;
+  double world_x = cam.half_width - x_offset;
+  double world_y = cam.half_height - y_offset;
+  V3 pixel = xf_point(cam.inv, v3(world_x, world_y, -1.0));
+  V3 origin = v3(cam.inv[3], cam.inv[7], cam.inv[11]);  // inv * point(0,0,0)
+  V3 direction = vnormalize(vsub(pixel, origin));
+  return {origin, direction};
+}
+
+// color.rs:148-155: `(val * 255.0) as u8` saturates, truncates, maps NaN to 0
+__device__ __forceinline__ uint8_t quantise(double val) {
+  if (val < 0.0) return 0;
+  double s = val * 255.0;
+  if (s != s) return 0;
+  if (s >= 255.0) return 255;
+  if (s <= 0.0) return 0;
+  return (uint8_t)(int)s;
+}
+
+}  // namespace rtd

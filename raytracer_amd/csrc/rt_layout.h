@@ -1,0 +1,85 @@
+// rt_layout.h — records of the committed scene as they lie in HBM (plain structs shared
+// by the host-side builders and the device code; no HIP dependency).
+#pragma once
+#include <stdint.h>
+
+namespace rtd {
+
+// ---------------------------------------------------------------------------------------
+// Scene records in HBM.  Per-kind tables ("SoA over shape kinds"); each record is a
+// 16-byte-aligned struct so a lane fetches it with dwordx4 loads.
+struct alignas(16) DGroup {
+  double inv[12];  // rows 0..2 of the inverse transform (row 3 is 0,0,0,1)
+  int32_t parent;
+  int32_t nchain;    // number of transforms from the root down to this group
+  int32_t chain[6];  // group indices, root first, this group last
+};
+struct alignas(16) DPrim {
+  double inv[12];
+  double minimum, maximum;
+  int32_t kind, material, parent, closed;
+  uint32_t order;  // position in the reference's depth-first leaf order
+  uint32_t pad[3];
+};
+struct alignas(16) DMesh {
+  int32_t group, material;
+  uint32_t order_base;  // leaf order of triangle 0
+  int32_t root;         // index of the root node in the node table
+  int32_t tri_base;     // first record in the triangle table
+  int32_t ntris;
+  int32_t pad[2];
+};
+// One triangle as the intersection test reads it: p1, e1 = p2-p1, e2 = p3-p1
+// (triangle.rs:49-50).  80 bytes.
+struct alignas(16) DTri {
+  double p1[3], e1[3], e2[3];
+  uint32_t orig;    // index in face order (for the leaf order and tie-breaks)
+  uint32_t smooth;  // 1: interpolate vertex normals, 0: flat normal
+};
+// Normals, fetched only for the final hit: n1,n2,n3 (smooth) or the flat normal in n[0..2].
+struct alignas(8) DTriN {
+  double n[9];
+};
+// Binary BVH node holding the boxes of BOTH children, so one 128-byte fetch decides
+// both.  Child c >= 0: inner node index.  Child c < 0: leaf, first triangle = -(c+1)
+// relative to the mesh's tri_base, count in n0/n1 (0 = empty child).
+struct alignas(128) DNode {
+  double lo0[3], hi0[3], lo1[3], hi1[3];
+  int32_t c0, c1, n0, n1;
+  int32_t pad[4];
+};
+struct alignas(16) DMaterial {
+  double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
+  double a[3], b[3];
+  double pinv[12];
+  int32_t pattern_kind;
+  int32_t pad[3];
+};
+struct alignas(16) DLight {
+  double intensity[3];
+  double pos[3];
+};
+struct DScene {
+  const DGroup* groups;
+  const DPrim* prims;
+  const DMesh* meshes;
+  const DTri* tris;
+  const DTriN* trin;
+  const DNode* nodes;
+  const DMaterial* mats;
+  const DLight* lights;
+  int32_t n_groups, n_prims, n_meshes, n_lights;
+};
+struct DCamera {
+  double inv[12];
+  double half_width, half_height, pixel_size;
+  int32_t hsize, vsize;
+};
+
+struct Counters {
+  unsigned long long rays_primary, rays_shadow, rays_reflect, rays_refract, depth0_skipped,
+      pred_queries, nodes_visited, tri_tests, prim_tests, inst_entries, shade_calls;
+};
+constexpr int N_COUNTERS = 11;
+
+}  // namespace rtd
