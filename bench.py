@@ -1,0 +1,204 @@
+"""bench.py — Mrays/s of the per-pixel render path on N MI355X.
+
+A step is one full frame of the workload (default: the configuration the metric is
+quoted on, the glass pawn at 1920x1080, depth 5, f64 parity mode) with the committed
+scene already resident in HBM.  With N > 1 the frame's 32x32-pixel tiles are dealt
+round-robin to the ranks (one process per GPU), every rank renders its tiles, and one RCCL
+gather + a de-tile kernel on rank 0 assemble the image inside the timed step ("strong"
+scaling: the frame is fixed, the GPUs share it).
+
+Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+WORKLOADS = {
+    # name: (example, hsize, vsize, synthetic_tris, description)
+    "cover400": ("cover", 400, 400, 0, "cover 400x400 (19 primitives, 2 lights)"),
+    "pawn1080": ("pawn", 1920, 1080, 0, "pawn 1920x1080 (31776 smooth triangles + plane, glass)"),
+    "teaset1080": ("tea set", 1920, 1080, 0, "tea set 1920x1080 (23076 smooth triangles in 3 instances + plane)"),
+    "pawn8k": ("pawn", 7680, 4320, 0, "pawn 7680x4320"),
+    "synthetic4k": ("synthetic", 3840, 2160, 1000000, "synthetic 1M flat triangles + 64 reflective spheres 3840x2160"),
+}
+
+# MI355X peaks: HBM3E 8 TB/s; FP64 vector 78.6 TFLOP/s (half the 157.3 TFLOP/s FP32 vector peak)
+PEAK_HBM_GBS = 8000.0
+PEAK_F64_TFLOPS = 78.6
+
+
+def algorithmic_work(st, node_bytes):
+    """Per-frame algorithmic bytes and flops from the traversal counters:
+    bytes = node_bytes*nodes + 72*tri_tests + 72*shaded mesh hits (normals);
+    flops = 36*nodes (two 18-flop box tests) + 46*tri_tests + 56*instance entries
+            + 30*primitive tests + 200*shade calls."""
+    b = node_bytes * st["nodes_visited"] + 72 * st["tri_tests"] + 72 * st["shade_calls"]
+    f = (36 * st["nodes_visited"] + 46 * st["tri_tests"] + 56 * st["inst_entries"] +
+         30 * st["prim_tests"] + 200 * st["shade_calls"])
+    return b, f
+
+
+def cpu_baseline(example, hs, vs, ntris, pixels):
+    """The CPU oracle (brute force, as the reference: every ray against every triangle) on a
+    strided sample of the frame's pixels, all host threads."""
+    from oracle import oracle as O
+    threads = O.default_threads()
+    sc = O.Scene.example(example, hs, vs, synthetic_tris=ntris)
+    if ntris:
+        sc.use_bvh()  # brute force over 1M triangles is not feasible; say so in `sample`
+    n = hs * vs
+    idx = (np.arange(pixels, dtype=np.int64) * (n // pixels) + (n // pixels) // 2) % n
+    xs, ys = (idx % hs).astype(np.int32), (idx // hs).astype(np.int32)
+    t0 = time.time()
+    _, _, cnt = sc.render_pixels(xs, ys, threads=threads)
+    dt = time.time() - t0
+    rays = cnt["primary"] + cnt["shadow"] + cnt["reflect"] + cnt["refract"]
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{pixels} pixels on a uniform stride over the {hs}x{vs} frame, "
+                      f"{rays} rays, {dt:.2f} s wall, "
+                      + ("oracle culling mode (brute force infeasible)" if ntris else
+                         "brute force over all triangles like the reference")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="pawn1080", choices=sorted(WORKLOADS))
+    ap.add_argument("--pipeline", default="megakernel", choices=["megakernel", "wavefront"])
+    ap.add_argument("--cpu-pixels", type=int, default=16384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import raytracer_amd as rt
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world_size > 1 else 0)
+
+    example, hs, vs, ntris, desc = WORKLOADS[args.workload]
+    pipeline = rt.PIPELINE_MEGAKERNEL if args.pipeline == "megakernel" else rt.PIPELINE_WAVEFRONT
+    w = rt.World.example(example, hs, vs, synthetic_tris=ntris).commit(device=dev.index)
+    info = w.info()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    n = world_size
+    per = max(rt.shard_tiles(hs, vs, s, n) for s in range(n))
+    image = torch.zeros((vs, hs, 3), dtype=torch.uint8, device=dev)
+    tiles = torch.zeros(per * rt.TILE * rt.TILE * 3, dtype=torch.uint8, device=dev) if n > 1 else None
+    gathered = ([torch.zeros_like(tiles) for _ in range(n)] if (n > 1 and rank == 0) else None)
+    all_tiles = torch.zeros((n, per * rt.TILE * rt.TILE * 3), dtype=torch.uint8, device=dev) if (n > 1 and rank == 0) else None
+
+    def step(want_stats=False):
+        if n == 1:
+            w.render_device(d_u8=image.data_ptr(), stream=stream, pipeline=pipeline, want_stats=want_stats)
+        else:
+            w.render_device(d_u8=tiles.data_ptr(), stream=stream, pipeline=pipeline, tile_first=rank,
+                            tile_step=n, want_stats=want_stats)
+            dist.gather(tiles, gathered, dst=0)
+            if rank == 0:
+                torch.stack(gathered, out=all_tiles)
+                rt.detile_u8(all_tiles.data_ptr(), n, per, hs, vs, image.data_ptr(), stream)
+
+    # counters of one frame (outside the timed region; deterministic per scene)
+    step(want_stats=True)
+    torch.cuda.synchronize()
+    st = w.stats().as_dict()
+    keys = ["rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "depth0_skipped", "pred_queries",
+            "nodes_visited", "tri_tests", "prim_tests", "inst_entries", "shade_calls"]
+    if n > 1:
+        t = torch.tensor([st[k] for k in keys], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        st.update({k: int(v) for k, v in zip(keys, t.tolist())})
+    rays_per_frame = st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"] + st["rays_refract"]
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if n > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        if n == 1:
+            step()
+            ev[i][1].record()
+        else:
+            w.render_device(d_u8=tiles.data_ptr(), stream=stream, pipeline=pipeline, tile_first=rank, tile_step=n)
+            ev[i][1].record()
+            dist.gather(tiles, gathered, dst=0)
+            if rank == 0:
+                torch.stack(gathered, out=all_tiles)
+                rt.detile_u8(all_tiles.data_ptr(), n, per, hs, vs, image.data_ptr(), stream)
+    torch.cuda.synchronize()
+    if n > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # this rank's render kernel(s)
+    if n > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = t.tolist()
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = rays_per_frame / (ms_per_step * 1e3)
+        abytes, aflops = algorithmic_work(st, info["node_bytes"])
+        # per launch: this rank's share of the frame (1/n of the counters for n > 1)
+        ach_gbs = abytes / n / (kernel_ms * 1e-3) / 1e9
+        ach_tf = aflops / n / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mrays/s (primary+shadow+reflection+refraction), pawn @1080p" if args.workload == "pawn1080"
+                      else f"Mrays/s (primary+shadow+reflection+refraction), {args.workload}",
+            "value": value, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "hsize": hs, "vsize": vs, "depth": 5, "mode": "f64_parity",
+                       "pipeline": args.pipeline, "rays_per_frame": rays_per_frame,
+                       "parallelism": f"tiles{rt.TILE}x{rt.TILE} round-robin over {n} GPU(s)" + (", RCCL gather to rank 0" if n > 1 else ""),
+                       "triangles": info["n_triangles"], "bvh_nodes": info["n_bvh_nodes"],
+                       "scene_bytes": info["device_bytes"]},
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / PEAK_HBM_GBS, "traffic": None,
+                         "kernel": "k_render_mega" if args.pipeline == "megakernel" else "wavefront kernels",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes / n,
+                         "note": "algorithmic bytes = node_bytes*nodes_visited + 72*tri_tests + 72*shade_calls; "
+                                 "the working set is L2/MALL resident, so HBM is not what binds this kernel"},
+            "roofline_valu_f64": {"bound": "valu_f64", "achieved": ach_tf, "peak": PEAK_F64_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": ach_tf / PEAK_F64_TFLOPS,
+                                  "algorithmic_flops_per_launch": aflops / n},
+            "counters_per_frame": {k: st[k] for k in keys},
+        }
+        if n == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(example, hs, vs, ntris, args.cpu_pixels)
+        print(json.dumps(out), flush=True)
+    if n > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -114,6 +114,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RtError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
                       f"g.build()'` (or `make -C raytracer_amd`) first")
+    # PyTorch ships its own copy of the HIP runtime.  Load it first so the process holds ONE
+    # runtime: device pointers and streams handed over by torch then belong to the runtime
+    # the kernels are launched with (loading ours first leaves torch without visible GPUs).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     dp, u8p, vp = C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.c_void_p
     L.rt_last_error.restype = C.c_char_p

@@ -148,20 +148,20 @@ k_render_mega(DScene S, DCamera cam, PixelMap pm, int depth, double* out_f64, ui
   flush_counters<STATS>(cnt, counters);
 }
 
-__global__ void k_trace_rays(DScene S, long long n, const double* origins, const double* dirs,
+__global__ void __launch_bounds__(64) k_trace_rays(DScene S, long long n, const double* origins, const double* dirs,
                              int depth, double* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Counters cnt{};
   Ray r = {v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
            v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2])};
-  ShadeOut so{};
-  HitRec h{};
-  bool found = false;
-  C3 c = color_at<false>(S, r, depth, cnt, &so, &h, &found);
   double* o = out + 32 * i;
   for (int k = 0; k < 32; k++) o[k] = 0.0;
-  if (!found) return;
+  HitRec h;
+  if (!trace_closest<false>(S, r, h, cnt)) return;
+  ShadeOut so;
+  shade_hit_local<false>(S, r, h, so, cnt);
+  C3 c = color_at<false>(S, r, depth, cnt);
   o[0] = 1.0;
   o[1] = h.t;
   o[2] = (double)h.order;

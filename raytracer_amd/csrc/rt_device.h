@@ -903,9 +903,7 @@ constexpr int MAX_DEPTH = 8;
 
 // World::color_at(ray, depth) with the recursion unrolled onto an explicit stack.
 template <bool STATS>
-__device__ inline C3 color_at(const DScene& S, Ray ray, int depth, Counters& cnt,
-                              ShadeOut* first_out = nullptr, HitRec* first_hit = nullptr,
-                              bool* first_found = nullptr) {
+__device__ inline C3 color_at(const DScene& S, Ray ray, int depth, Counters& cnt) {
   Frame frames[MAX_DEPTH];
   int level = 0;
   C3 ret = {0.0, 0.0, 0.0};
@@ -916,16 +914,11 @@ __device__ inline C3 color_at(const DScene& S, Ray ray, int depth, Counters& cnt
     // ---- enter color_at(ray, remaining), remaining >= 1 or the top-level call
     HitRec h;
     bool found = trace_closest<STATS>(S, ray, h, cnt);
-    if (level == 0 && first_found) *first_found = found;
     bool returning = true;
-    if (found && (remaining > 0 || (level == 0 && first_out))) {
+    if (found && remaining > 0) {
       ShadeOut so;
       shade_hit_local<STATS>(S, ray, h, so, cnt);
-      if (level == 0 && first_out) {
-        *first_out = so;
-        *first_hit = h;
-      }
-      if (remaining > 0) {
+      {
         Frame& F = frames[level];
         F.surface = so.surface;
         F.reflected = {0.0, 0.0, 0.0};
@@ -956,8 +949,6 @@ __device__ inline C3 color_at(const DScene& S, Ray ray, int depth, Counters& cnt
         if (so.do_refract && STATS) cnt.depth0_skipped++;
         C3 zero = {0.0, 0.0, 0.0};
         ret = combine(F.surface, zero, zero, F.use_schlick, F.reflectance);
-      } else {
-        ret = {0.0, 0.0, 0.0};
       }
     } else {
       ret = {0.0, 0.0, 0.0};  // world.rs:74 (no hit) or world.rs:37-39 (depth 0)

@@ -1,0 +1,310 @@
+"""Parity of the HIP render core (through the C ABI) with the CPU oracle and with the
+reference's own committed renders.  All tests need an MI355X: `pytest -m gpu`.
+
+Bars (BASELINE.json north_star): after 8-bit quantisation >= 99.9 % of the pixels equal,
+<= 1/255 on the rest.  The f64 path reaches more: geometry decisions are bit-identical, so
+every pixel is equal; the f64 colours differ from the oracle's only through pow() in the
+specular term (device libm vs glibc), bounded here by 1e-12.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+F64_TOL = 1e-12
+S2 = math.sqrt(2.0)
+
+
+def u8_report(a, b):
+    d = np.abs(a.astype(np.int32) - b.astype(np.int32)).max(axis=-1)
+    return float((d == 0).mean()), int(d.max())
+
+
+def build_both(rt, O, builder, *args, **kw):
+    w = rt.World()
+    builder(w, rt.material, rt, *args, **kw)
+    s = O.Scene()
+    builder(s, O.material, rt, *args, **kw)  # same matrices (product's host math) on both sides
+    w.commit()
+    return w, s
+
+
+# ---- the reference's own renders -------------------------------------------------------------
+@pytest.mark.parametrize("name", ["cover", "pawn", "tea set"])
+def test_default_size_render_equals_reference_png(rt, O, name):
+    gold = O.golden_image(name)
+    w = rt.World.example(name).commit()
+    u8, _, _ = w.render()
+    exact, worst = u8_report(u8, gold)
+    assert exact >= 0.999 and worst <= 1, (exact, worst)
+    assert exact == 1.0
+
+
+# ---- BASELINE.json configs against the oracle ---------------------------------------------
+def test_cover_400_full_image_and_counters(rt, O):
+    w = rt.World.example("cover", 400, 400).commit()
+    u8, f64, st = w.render(want_f64=True, want_stats=True)
+    of64, ou8, cnt = O.Scene.example("cover", 400, 400).render()
+    assert np.array_equal(u8, ou8)
+    assert np.abs(f64 - of64).max() <= F64_TOL
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect, st.rays_refract, st.depth0_skipped) == (
+        cnt["primary"], cnt["shadow"], cnt["reflect"], cnt["refract"], cnt["depth0"])
+
+
+@pytest.mark.parametrize("name", ["pawn", "tea set"])
+def test_1080p_full_image_vs_oracle(rt, O, name):
+    """Every pixel of the 1920x1080 configs: oracle in culling mode (bit-identical to its
+    brute-force mode, see test_oracle_kats.test_bvh_mode_is_bit_identical), plus a brute-force
+    sample."""
+    w = rt.World.example(name, 1920, 1080).commit()
+    u8, f64, st = w.render(want_f64=True, want_stats=True)
+    sc = O.Scene.example(name, 1920, 1080).use_bvh()
+    of64, ou8, cnt = sc.render()
+    assert np.array_equal(u8, ou8)
+    assert np.abs(f64 - of64).max() <= F64_TOL
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect, st.rays_refract, st.depth0_skipped) == (
+        cnt["primary"], cnt["shadow"], cnt["reflect"], cnt["refract"], cnt["depth0"])
+    brute = O.Scene.example(name, 1920, 1080)
+    rng = np.random.default_rng(5)
+    xs, ys = rng.integers(0, 1920, 600), rng.integers(0, 1080, 600)
+    bf, bu, _ = brute.render_pixels(xs, ys)
+    assert np.array_equal(bu, u8[ys, xs])
+    assert np.abs(bf - f64[ys, xs]).max() <= F64_TOL
+
+
+def test_test_scene_cylinders_cones_patterns(rt, O):
+    """examples.rs:270-404 (unreachable from the reference CLI): cylinder, cone, Rings and
+    Checkered with pattern transforms, two transparent shapes."""
+    w = rt.World.example("test_scene", 480, 270).commit()
+    u8, f64, _ = w.render(want_f64=True)
+    of64, ou8, _ = O.Scene.example("test_scene", 480, 270).render()
+    assert np.array_equal(u8, ou8)
+    assert np.abs(f64 - of64).max() <= F64_TOL
+
+
+def test_synthetic_scene_small(rt, O):
+    """The stress scene at 20k triangles / 320x180: full image vs oracle culling mode and a
+    brute-force sample."""
+    w = rt.World.example("synthetic", 320, 180, synthetic_tris=20000).commit()
+    u8, f64, _ = w.render(want_f64=True)
+    sc = O.Scene.example("synthetic", 320, 180, synthetic_tris=20000).use_bvh()
+    of64, ou8, _ = sc.render()
+    assert np.array_equal(u8, ou8)
+    assert np.abs(f64 - of64).max() <= F64_TOL
+    brute = O.Scene.example("synthetic", 320, 180, synthetic_tris=20000)
+    rng = np.random.default_rng(9)
+    xs, ys = rng.integers(0, 320, 400), rng.integers(0, 180, 400)
+    bf, bu, _ = brute.render_pixels(xs, ys)
+    assert np.array_equal(bu, u8[ys, xs])
+
+
+# ---- random and adversarial scenes -------------------------------------------------------------
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_scenes(rt, O, seed):
+    w, s = build_both(rt, O, scenes.random_scene, seed)
+    u8, f64, _ = w.render(want_f64=True)
+    of64, ou8, cnt = s.render()
+    assert cnt["nan_t"] == 0
+    assert np.array_equal(u8, ou8)
+    assert np.abs(f64 - of64).max() <= 1e-11
+
+
+def test_equal_t_ties_resolved_by_leaf_order(rt, O):
+    w, s = build_both(rt, O, scenes.tie_scene)
+    u8, f64, _ = w.render(want_f64=True)
+    of64, ou8, _ = s.render()
+    assert np.array_equal(u8, ou8)
+    assert np.abs(f64 - of64).max() <= F64_TOL
+    # the first-added red cube wins over the coincident green one
+    assert (u8[..., 0] > 100).any() and not ((u8[..., 1] > 200) & (u8[..., 0] < 50) & (u8[..., 2] < 50)).any()
+
+
+# ---- single-ray known answers of the reference's tests, through rt_trace_rays ---------------
+def trace(w, o, d, depth=5):
+    r = w.trace_rays([o], [d], depth)[0]
+    return dict(hit=bool(r[0]), t=r[1], order=int(r[2]), u=r[3], v=r[4], inside=bool(r[5]), n1=r[6],
+                n2=r[7], point=r[8:11], over=r[11:14], under=r[14:17], eyev=r[17:20], normalv=r[20:23],
+                reflectv=r[23:26], schlick=r[26], color=r[27:30], shadowed=bool(r[30]))
+
+
+def close(a, b, eps=1e-5):
+    return np.all(np.abs(np.asarray(a, dtype=float) - np.asarray(b, dtype=float)) < eps)
+
+
+def test_kat_default_world(rt, O):  # world.rs:206-269, 317-354
+    w, s = build_both(rt, O, scenes.populated_world)
+    r = trace(w, (0, 0, -5), (0, 0, 1))
+    assert r["hit"] and abs(r["t"] - 4.0) < 1e-5 and r["order"] == 0
+    assert close(r["color"], (0.38066, 0.47583, 0.2855))
+    assert not trace(w, (0, 0, -5), (0, 1, 0))["hit"]
+    assert close(r["point"], (0, 0, -1)) and close(r["eyev"], (0, 0, -1)) and close(r["normalv"], (0, 0, -1))
+    # against the oracle bit for bit (no specular pow on this path except the lit sphere)
+    oi = s.trace_info((0, 0, -5), (0, 0, 1))
+    for k, ok in (("point", "point"), ("over", "over_point"), ("under", "under_point"),
+                  ("normalv", "normalv"), ("reflectv", "reflectv")):
+        assert np.array_equal(r[k], oi[ok]), k
+    assert r["t"] == oi["t"]
+
+
+def test_kat_reflective_plane(rt, O):  # world.rs:339-354
+    def b(T, M, X):
+        scenes.populated_world(T, M, X)
+        T.add_shape(scenes.PLANE, X.translation(0, -1, 0), M(reflective=0.5))
+    w, s = build_both(rt, O, b)
+    r = trace(w, (0, 0, -3), (0, -S2 / 2, S2 / 2))
+    assert close(r["color"], (0.8767572837020907, 0.924340334075874, 0.8291742333283075), 1e-9)
+    assert close(r["reflectv"], (0, S2 / 2, S2 / 2))
+
+
+def test_kat_n1_n2_nested_glass(rt, O):  # intersect.rs:378-406
+    w, s = build_both(rt, O, scenes.glass_spheres)
+    expected = [(1.0, 1.5), (1.5, 2.0), (2.0, 2.5), (2.5, 2.5), (2.5, 1.5), (1.5, 1.0)]
+    for z0, (n1, n2) in zip((-4.0, -1.5, -1.0, 0.5, 1.0, 1.5), expected):
+        r = trace(w, (0, 0, z0), (0, 0, 1))
+        assert r["n1"] == n1 and r["n2"] == n2, (z0, r["n1"], r["n2"])
+
+
+def test_kat_transparent_floor_and_schlick(rt, O):  # world.rs:386-441
+    def floor(reflective):
+        def b(T, M, X):
+            scenes.populated_world(T, M, X)
+            T.add_shape(scenes.PLANE, X.translation(0, -1, 0),
+                        M(transparency=0.5, refractive_index=1.5, reflective=reflective))
+            T.add_shape(scenes.SPHERE, X.translation(0, -3.5, -0.5), M(a=(1, 0, 0), ambient=0.5))
+        return b
+    w, _ = build_both(rt, O, floor(0.0))
+    assert close(trace(w, (0, 0, -3), (0, -S2 / 2, S2 / 2))["color"], (0.93642, 0.68642, 0.68642))
+    w, _ = build_both(rt, O, floor(0.5))
+    assert close(trace(w, (0, 0, -3), (0, -S2 / 2, S2 / 2))["color"], (0.93391, 0.69643, 0.69243))
+
+    def glass(T, M, X):
+        T.add_shape(scenes.SPHERE, None, M(transparency=1.0, refractive_index=1.5, reflective=0.5, a=(0, 0, 0)))
+        T.add_light((1, 1, 1), (-10, 10, -10))
+    w, s = build_both(rt, O, glass)
+    r = trace(w, (0, 0.99, -2.0), (0, 0, 1))
+    assert abs(r["schlick"] - 0.4888143830387389) < 1e-5
+    assert r["schlick"] == s.trace_info((0, 0.99, -2.0), (0, 0, 1))["schlick"]
+
+
+def test_kat_shadows(rt, O):  # world.rs:272-297: the four is_shadowed cases
+    def b(T, M, X):
+        scenes.populated_world(T, M, X)
+        # a big far plane only to give the probe rays something to hit near the test points
+    w, s = build_both(rt, O, b)
+    # probe: rays whose first hit's over_point is then tested towards light 0
+    for o, d in (((0, 0, -5), (0, 0, 1)), ((0, 0, 5), (0, 0, -1)), ((5, 0.2, 0), (-1, 0, 0))):
+        r = trace(w, o, d)
+        oi = s.trace_info(o, d)
+        assert r["shadowed"] == s.is_shadowed(oi["over_point"])
+
+
+def test_kat_nested_group_normal(rt, O):  # group.rs:186-219
+    w, s = build_both(rt, O, scenes.nested_groups)
+    target = np.array([1.7321, 1.1547, -5.5774])
+    o = target * 3.0
+    d = (target - o) / np.linalg.norm(target - o)
+    r, oi = trace(w, o, d), s.trace_info(o, d)
+    assert r["hit"] and np.array_equal(r["normalv"], oi["normalv"]) and r["t"] == oi["t"]
+    assert close(r["normalv"], (0.28570368184140726, 0.42854315178114105, -0.8571605294481017), 2e-4)
+
+
+def test_kat_smooth_triangle(rt, O):  # smooth_triangle.rs:175-200
+    def b(T, M, X):
+        g = T.add_group()
+        T.add_triangle([0, 1, 0, -1, 0, 0, 1, 0, 0], [0, 1, 0, -1, 0, 0, 1, 0, 0], parent=g)
+        T.add_light((1, 1, 1), (-10, 10, -10))
+    w, s = build_both(rt, O, b)
+    r = trace(w, (-0.2, 0.3, -2.0), (0, 0, 1))
+    assert abs(r["u"] - 0.45) < 1e-5 and abs(r["v"] - 0.25) < 1e-5
+    assert close(r["normalv"], (-0.5547, 0.83205, 0.0))
+
+
+def test_many_random_rays_bitwise(rt, O):
+    """20k random rays through the pawn scene: hit t, u, v, n1/n2, normal and the offset points
+    must equal the oracle's bit for bit (everything up to the specular pow)."""
+    w = rt.World.example("pawn", 64, 64).commit()
+    s = O.Scene.example("pawn", 64, 64).use_bvh()
+    rng = np.random.default_rng(77)
+    n = 4000
+    o = np.stack([rng.uniform(-3, 3, n), rng.uniform(0.2, 5, n), rng.uniform(-5, 3, n)], axis=1)
+    tgt = np.stack([rng.uniform(-0.8, 0.8, n), rng.uniform(0, 2.5, n), rng.uniform(-0.8, 0.8, n)], axis=1)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    out = w.trace_rays(o, d)
+    hits = 0
+    for i in range(n):
+        oi = s.trace_info(o[i], d[i])
+        assert bool(out[i, 0]) == oi["hit"]
+        if not oi["hit"]:
+            continue
+        hits += 1
+        assert out[i, 1] == oi["t"] and out[i, 3] == oi["u"] and out[i, 4] == oi["v"]
+        assert np.array_equal(out[i, 20:23], oi["normalv"])
+        assert np.array_equal(out[i, 11:14], oi["over_point"])
+        if int(out[i, 2]) < 31776:  # glass triangle: the device evaluates n1/n2 (plane: unused)
+            assert out[i, 6] == oi["n1"] and out[i, 7] == oi["n2"]
+    assert hits > n // 2
+
+
+# ---- edge cases --------------------------------------------------------------------------------
+def test_empty_world_and_no_lights(rt, O):
+    w = rt.World()
+    w.set_camera(33, 17, 1.0)
+    w.commit()
+    u8, f64, st = w.render(want_f64=True, want_stats=True)
+    assert u8.shape == (17, 33, 3) and not u8.any() and not f64.any()
+    assert st.rays_primary == 33 * 17 and st.rays_shadow == 0
+
+    def b(T, M, X):  # objects but no light: every pixel black, no shadow rays
+        T.add_shape(scenes.SPHERE, None, M(reflective=0.5))
+        T.set_camera(16, 16, 1.0, X.view_transform((0, 0, -5), (0, 0, 0), (0, 1, 0)))
+    w, s = build_both(rt, O, b)
+    u8, _, _ = w.render()
+    assert np.array_equal(u8, s.render()[1])
+
+
+@pytest.mark.parametrize("size", [(1, 1), (7, 3), (31, 33), (65, 64), (100, 1)])
+def test_ragged_image_sizes(rt, O, size):
+    w = rt.World.example("cover", *size).commit()
+    u8, f64, _ = w.render(want_f64=True)
+    of64, ou8, _ = O.Scene.example("cover", *size).render()
+    assert np.array_equal(u8, ou8) and np.abs(f64 - of64).max() <= F64_TOL
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2, 3, 8])
+def test_recursion_depths(rt, O, depth):
+    w = rt.World.example("cover", 96, 96).commit()
+    u8, _, st = w.render(depth=depth, want_stats=True)
+    _, ou8, cnt = O.Scene.example("cover", 96, 96).render(depth=depth)
+    assert np.array_equal(u8, ou8)
+    if depth > 0:
+        assert st.rays() == cnt["primary"] + cnt["shadow"] + cnt["reflect"] + cnt["refract"]
+
+
+def test_repeated_renders_are_deterministic(rt):
+    w = rt.World.example("pawn", 320, 240).commit()
+    a = w.render(want_f64=True)
+    b = w.render(want_f64=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ---- tile shards (the multi-GPU decomposition) on one GPU ------------------------------------
+@pytest.mark.parametrize("nshards", [2, 3, 8])
+def test_tile_shards_stitch_to_the_full_image(rt, nshards):
+    import torch
+    name, hs, vs = "pawn", 250, 141  # ragged: partial tiles on both edges
+    w = rt.World.example(name, hs, vs).commit()
+    full, _, _ = w.render()
+    per = max(rt.shard_tiles(hs, vs, s, nshards) for s in range(nshards))
+    tiles = torch.zeros((nshards, per * rt.TILE * rt.TILE * 3), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for s in range(nshards):
+        w.render_device(d_u8=tiles[s].data_ptr(), stream=stream, tile_first=s, tile_step=nshards)
+    img = torch.zeros((vs, hs, 3), dtype=torch.uint8, device="cuda")
+    rt.detile_u8(tiles.data_ptr(), nshards, per, hs, vs, img.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(img.cpu().numpy(), full)
