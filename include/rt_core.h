@@ -131,6 +131,7 @@ typedef struct rt_stats {
   uint64_t launches;      /* kernel launches issued */
   double kernel_ms;       /* HIP-event time of the render kernels on their stream */
   double total_ms;        /* host wall time of the call */
+  uint64_t max_nodes_per_query; /* largest BVH node count one traversal needed */
 } rt_stats;
 
 /* scene info after commit */

@@ -15,7 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "libraytracer_amd.so")
+LIB_PATH = os.environ.get("RT_LIB") or os.path.join(HERE, "libraytracer_amd.so")  # RT_LIB: A/B builds
 OBJ_DIR = os.path.join(REPO, "assets", "obj")
 
 SPHERE, PLANE, CUBE, CYLINDER, CONE = range(5)
@@ -69,7 +69,8 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "depth0_skipped",
         "pred_queries", "nodes_visited", "tri_tests", "prim_tests", "inst_entries", "shade_calls",
-        "launches")] + [("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+        "launches")] + [("kernel_ms", C.c_double), ("total_ms", C.c_double),
+                        ("max_nodes_per_query", C.c_uint64)]
 
     def rays(self):
         return self.rays_primary + self.rays_shadow + self.rays_reflect + self.rays_refract
@@ -79,6 +80,7 @@ class Stats(C.Structure):
         d["kernel_ms"] = float(self.kernel_ms)
         d["total_ms"] = float(self.total_ms)
         d["rays"] = int(self.rays())
+        d["max_nodes_per_query"] = int(self.max_nodes_per_query)
         return d
 
 

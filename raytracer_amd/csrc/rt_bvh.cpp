@@ -159,12 +159,24 @@ struct Builder {
   }
 };
 
+// largest float <= x / smallest float >= x
+float round_down(double x) {
+  float f = (float)x;
+  if ((double)f > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+  return f;
+}
+float round_up(double x) {
+  float f = (float)x;
+  if ((double)f < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+  return f;
+}
+
 void set_child(rtd::DNode& N, int which, const Box& b, double pad, int child, int count) {
-  double* lo = which == 0 ? N.lo0 : N.lo1;
-  double* hi = which == 0 ? N.hi0 : N.hi1;
+  float* lo = which == 0 ? N.lo0 : N.lo1;
+  float* hi = which == 0 ? N.hi0 : N.hi1;
   for (int a = 0; a < 3; a++) {
-    lo[a] = b.lo[a] - pad;
-    hi[a] = b.hi[a] + pad;
+    lo[a] = round_down(b.lo[a] - pad);
+    hi[a] = round_up(b.hi[a] + pad);
   }
   if (which == 0) {
     N.c0 = child;
@@ -176,11 +188,12 @@ void set_child(rtd::DNode& N, int which, const Box& b, double pad, int child, in
 }
 
 void set_empty(rtd::DNode& N, int which) {
-  double* lo = which == 0 ? N.lo0 : N.lo1;
-  double* hi = which == 0 ? N.hi0 : N.hi1;
+  // an inverted, finite box: every slab interval over it is empty
+  float* lo = which == 0 ? N.lo0 : N.lo1;
+  float* hi = which == 0 ? N.hi0 : N.hi1;
   for (int a = 0; a < 3; a++) {
-    lo[a] = std::numeric_limits<double>::infinity();
-    hi[a] = -std::numeric_limits<double>::infinity();
+    lo[a] = std::numeric_limits<float>::max();
+    hi[a] = -std::numeric_limits<float>::max();
   }
   if (which == 0) {
     N.c0 = -1;
@@ -221,6 +234,11 @@ void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, 
     B.idx[t] = (uint32_t)t;
   }
   double pad = scale * BOX_PAD_REL + 1e-300;
+  out.scale = scale;
+  for (int a = 0; a < 3; a++) {
+    out.lo[a] = 0.0;
+    out.hi[a] = 0.0;
+  }
   rtd::DNode zero{};
   if (n == 0) {
     rtd::DNode N = zero;
@@ -233,12 +251,17 @@ void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, 
   int root = B.build(0, (int)n, 0);
   out.max_depth = B.max_depth;
   out.order = B.idx;
+  for (int a = 0; a < 3; a++) {
+    // root bounds as wide as the widest f32 child box can get
+    out.lo[a] = (double)round_down(B.tmp[root].box.lo[a] - pad) - pad;
+    out.hi[a] = (double)round_up(B.tmp[root].box.hi[a] + pad) + pad;
+  }
 
   // Convert: every inner tmp node becomes one DNode carrying its two children's boxes.
   const TmpNode& R = B.tmp[root];
   if (R.left < 0) {  // the whole mesh is one leaf
     rtd::DNode N = zero;
-    set_child(N, 0, R.box, pad, -(R.first + 1), R.count);
+    set_child(N, 0, R.box, pad, -2 - ((R.first << 3) | R.count), R.count);
     set_empty(N, 1);
     out.nodes.push_back(N);
     return;
@@ -265,11 +288,11 @@ void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, 
     if (L.left >= 0)
       set_child(N, 0, L.box, pad, map[T.left], 0);
     else
-      set_child(N, 0, L.box, pad, -(L.first + 1), L.count);
+      set_child(N, 0, L.box, pad, -2 - ((L.first << 3) | L.count), L.count);
     if (Rr.left >= 0)
       set_child(N, 1, Rr.box, pad, map[T.right], 0);
     else
-      set_child(N, 1, Rr.box, pad, -(Rr.first + 1), Rr.count);
+      set_child(N, 1, Rr.box, pad, -2 - ((Rr.first << 3) | Rr.count), Rr.count);
   }
 }
 

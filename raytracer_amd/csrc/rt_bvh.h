@@ -15,6 +15,8 @@ struct BuildResult {
   std::vector<rtd::DNode> nodes;  // nodes[0] is the root; child indices are local to this vector
   std::vector<uint32_t> order;    // order[k] = face index of the k-th triangle record
   int max_depth = 0;
+  double lo[3], hi[3];  // padded bounds of the whole mesh
+  double scale = 0.0;   // largest |coordinate|
 };
 
 // p1,p2,p3: n x 3 doubles.  max_leaf: triangles per leaf (<= 4).

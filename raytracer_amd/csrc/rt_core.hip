@@ -60,6 +60,13 @@ struct rt_scene {
   double* d_out_f64 = nullptr;
   uint8_t* d_out_u8 = nullptr;
   size_t out_cap_px = 0;
+  // wavefront pipeline: per-level ray queues and result nodes (grow only)
+  void* wf_tasks[MAX_DEPTH + 1] = {};
+  void* wf_nodes[MAX_DEPTH + 1] = {};
+  size_t wf_task_cap[MAX_DEPTH + 1] = {};
+  size_t wf_node_cap[MAX_DEPTH + 1] = {};
+  unsigned int* wf_counts = nullptr;       // device, one counter per level
+  unsigned int* wf_counts_host = nullptr;  // pinned
 };
 
 static bool affine_rows(const double* m16, double* out12, std::string& why) {
@@ -119,6 +126,7 @@ __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long 
     unsigned long long s = wave_sum(src[i]);
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(&g[i], s);
   }
+  if (c.max_nodes) atomicMax(&g[N_COUNTERS], c.max_nodes);
 }
 
 // render_thread (camera.rs:165-184): ray_for_pixel + color_at(ray, depth) + write_pixel,
@@ -127,13 +135,17 @@ template <bool STATS>
 __global__ void __launch_bounds__(64)
 k_render_mega(DScene S, DCamera cam, PixelMap pm, int depth, double* out_f64, uint8_t* out_u8,
               unsigned long long* counters) {
+  __shared__ int lds_stack[LDS_STACK * 64];
+  TravStack st;
+  st.lds = lds_stack + threadIdx.x;
+  st.stride = 64;
   Counters cnt{};
   int px, py;
   long long oi;
   bool active = lane_pixel(pm, px, py, oi);
   if (active) {
     Ray r = ray_for_pixel(cam, px, py);
-    C3 c = color_at<STATS>(S, r, depth, cnt);
+    C3 c = color_at<STATS>(S, r, depth, cnt, st);
     if (out_f64) {
       out_f64[oi * 3 + 0] = c.r;
       out_f64[oi * 3 + 1] = c.g;
@@ -152,16 +164,20 @@ __global__ void __launch_bounds__(64) k_trace_rays(DScene S, long long n, const 
                              int depth, double* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  __shared__ int lds_stack[LDS_STACK * 64];
+  TravStack st;
+  st.lds = lds_stack + threadIdx.x;
+  st.stride = 64;
   Counters cnt{};
   Ray r = {v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
            v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2])};
   double* o = out + 32 * i;
   for (int k = 0; k < 32; k++) o[k] = 0.0;
   HitRec h;
-  if (!trace_closest<false>(S, r, h, cnt)) return;
+  if (!trace_closest<false>(S, r, h, cnt, st)) return;
   ShadeOut so;
-  shade_hit_local<false>(S, r, h, so, cnt);
-  C3 c = color_at<false>(S, r, depth, cnt);
+  shade_hit_local<false>(S, r, h, so, cnt, st);
+  C3 c = color_at<false>(S, r, depth, cnt, st);
   o[0] = 1.0;
   o[1] = h.t;
   o[2] = (double)h.order;
@@ -185,7 +201,7 @@ __global__ void __launch_bounds__(64) k_trace_rays(DScene S, long long n, const 
     V3 v = vsub(lpos, so.over_point);
     double distance = vmag(v);
     Ray sr = {so.over_point, v3(v.x / distance, v.y / distance, v.z / distance)};
-    o[30] = trace_any<false>(S, sr, distance, cnt) ? 1.0 : 0.0;
+    o[30] = trace_any<false>(S, sr, distance, cnt, st) ? 1.0 : 0.0;
   }
 }
 
@@ -204,6 +220,171 @@ __global__ void k_detile_u8(const uint8_t* tiles, int nshards, long long tiles_p
   image[3 * i + 0] = tiles[3 * src + 0];
   image[3 * i + 1] = tiles[3 * src + 1];
   image[3 * i + 2] = tiles[3 * src + 2];
+}
+
+
+// =======================================================================================
+// Wavefront pipeline.  The recursion tree of color_at (world.rs:67-114) is evaluated level
+// by level: level L holds every color_at call whose remaining depth is depth-L.  One lane
+// per call: trace, shade, append the reflected / refracted child rays to the next level's
+// queue.  When the deepest level is done the results flow back up, one combine pass per
+// level, each node evaluating exactly the expression of world.rs:57-64 on its children's
+// results — so the colours are the same bits as the recursive evaluation, while expensive
+// pixels (glass: ~18 rays) are spread over many lanes instead of serialising one.
+struct alignas(16) WfTask {
+  double o[3], d[3];
+  double coef;     // what the parent multiplies this call's colour by (reflective / transparency)
+  int32_t parent;  // node index in the previous level
+  uint32_t slot;   // 0: the parent's reflected colour, 1: its refracted colour
+};
+struct alignas(16) WfNode {
+  double surface[3], reflected[3], refracted[3];
+  double reflectance, coef;
+  int32_t parent;  // previous-level node, or the output pixel index at level 0 (-1: no pixel)
+  uint32_t flags;  // bit0: hit (otherwise the call returned black), bit1: Schlick mix, bit2: slot
+};
+constexpr int WF_BLOCK = 64;
+
+#ifndef WF_WAVES
+#define WF_WAVES 2
+#endif
+template <bool STATS, bool PRIMARY>
+__global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
+k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n, WfNode* nodes,
+           WfTask* next, unsigned int* next_count, unsigned int next_cap, int spawn,
+           unsigned long long* counters) {
+  __shared__ int lds_stack[LDS_STACK * WF_BLOCK];
+  TravStack st;
+  st.lds = lds_stack + threadIdx.x;
+  st.stride = WF_BLOCK;
+  Counters cnt{};
+  long long i = (long long)blockIdx.x * WF_BLOCK + threadIdx.x;
+  bool active;
+  Ray ray;
+  WfNode nd;
+  nd.flags = 0;
+  nd.coef = 0.0;
+  nd.parent = -1;
+  if (PRIMARY) {
+    int px, py;
+    long long oi;
+    active = lane_pixel(pm, px, py, oi);
+    if (active) {
+      ray = ray_for_pixel(cam, px, py);
+      nd.parent = (int32_t)oi;
+      if (STATS) cnt.rays_primary++;
+    }
+  } else {
+    active = i < n;
+    if (active) {
+      const WfTask& T = tasks[i];
+      ray = {v3(T.o[0], T.o[1], T.o[2]), v3(T.d[0], T.d[1], T.d[2])};
+      nd.parent = T.parent;
+      nd.coef = T.coef;
+      nd.flags = T.slot << 2;
+      if (STATS) {
+        if (T.slot)
+          cnt.rays_refract++;
+        else
+          cnt.rays_reflect++;
+      }
+    }
+  }
+  if (active) {
+    HitRec h;
+    if (trace_closest<STATS>(S, ray, h, cnt, st)) {
+      ShadeOut so;
+      shade_hit_local<STATS>(S, ray, h, so, cnt, st);
+      nd.surface[0] = so.surface.r;
+      nd.surface[1] = so.surface.g;
+      nd.surface[2] = so.surface.b;
+      nd.reflectance = so.reflectance;
+      nd.flags |= 1u | (so.use_schlick ? 2u : 0u);
+      for (int k = 0; k < 3; k++) {
+        nd.reflected[k] = 0.0;
+        nd.refracted[k] = 0.0;
+      }
+      if (so.do_reflect) {
+        if (spawn) {
+          unsigned int idx = atomicAdd(next_count, 1u);
+          if (idx < next_cap) {
+            WfTask& T = next[idx];
+            T.o[0] = so.reflect_ray.o.x;
+            T.o[1] = so.reflect_ray.o.y;
+            T.o[2] = so.reflect_ray.o.z;
+            T.d[0] = so.reflect_ray.d.x;
+            T.d[1] = so.reflect_ray.d.y;
+            T.d[2] = so.reflect_ray.d.z;
+            T.coef = so.reflective;
+            T.parent = (int32_t)i;
+            T.slot = 0;
+          }
+        } else if (STATS) {
+          cnt.depth0_skipped++;
+        }
+      }
+      if (so.do_refract) {
+        if (spawn) {
+          unsigned int idx = atomicAdd(next_count, 1u);
+          if (idx < next_cap) {
+            WfTask& T = next[idx];
+            T.o[0] = so.refract_ray.o.x;
+            T.o[1] = so.refract_ray.o.y;
+            T.o[2] = so.refract_ray.o.z;
+            T.d[0] = so.refract_ray.d.x;
+            T.d[1] = so.refract_ray.d.y;
+            T.d[2] = so.refract_ray.d.z;
+            T.coef = so.transparency;
+            T.parent = (int32_t)i;
+            T.slot = 1;
+          }
+        } else if (STATS) {
+          cnt.depth0_skipped++;
+        }
+      }
+    }
+  }
+  if (PRIMARY || active) nodes[i] = nd;
+  flush_counters<STATS>(cnt, counters);
+}
+
+// One level of the way back up: ret = shade_hit's final expression (world.rs:57-64); level 0
+// writes the pixel (canvas.rs:21 + color.rs:148-155), other levels hand `ret * coef`
+// (world.rs:85 / 112) to the parent's slot.
+template <bool LEVEL0>
+__global__ void k_wf_combine(const WfNode* nodes, long long n, WfNode* parents, double* out_f64,
+                             uint8_t* out_u8) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const WfNode& N = nodes[i];
+  if (N.parent < 0) return;
+  C3 ret = {0.0, 0.0, 0.0};
+  bool hit = N.flags & 1u;
+  if (hit) {
+    C3 s = {N.surface[0], N.surface[1], N.surface[2]};
+    C3 rl = {N.reflected[0], N.reflected[1], N.reflected[2]};
+    C3 rr = {N.refracted[0], N.refracted[1], N.refracted[2]};
+    ret = combine(s, rl, rr, (N.flags & 2u) != 0, N.reflectance);
+  }
+  if (LEVEL0) {
+    long long oi = N.parent;
+    if (out_f64) {
+      out_f64[oi * 3 + 0] = ret.r;
+      out_f64[oi * 3 + 1] = ret.g;
+      out_f64[oi * 3 + 2] = ret.b;
+    }
+    if (out_u8) {
+      out_u8[oi * 3 + 0] = quantise(ret.r);
+      out_u8[oi * 3 + 1] = quantise(ret.g);
+      out_u8[oi * 3 + 2] = quantise(ret.b);
+    }
+  } else if (hit) {
+    WfNode& P = parents[N.parent];
+    double* dst = (N.flags & 4u) ? P.refracted : P.reflected;
+    dst[0] = ret.r * N.coef;
+    dst[1] = ret.g * N.coef;
+    dst[2] = ret.b * N.coef;
+  }
 }
 
 template <typename T>
@@ -243,6 +424,12 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->d_out_u8) (void)hipFree(s->d_out_u8);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    for (int l = 0; l <= MAX_DEPTH; l++) {
+      if (s->wf_tasks[l]) (void)hipFree(s->wf_tasks[l]);
+      if (s->wf_nodes[l]) (void)hipFree(s->wf_nodes[l]);
+    }
+    if (s->wf_counts) (void)hipFree(s->wf_counts);
+    if (s->wf_counts_host) (void)hipHostFree(s->wf_counts_host);
     (void)hipSetDevice(cur);
   }
   delete s;
@@ -298,7 +485,7 @@ int rt_scene_add_mesh(rt_scene* s, const rt_mesh* m) {
     return -fail(RT_ERR_ARG, "mesh group out of range");
   if (m->material < 0 || m->material >= (int)s->mats.size())
     return -fail(RT_ERR_ARG, "mesh material out of range");
-  if (m->ntris < 0 || m->ntris > 0x7fffff00LL) return -fail(RT_ERR_ARG, "bad triangle count");
+  if (m->ntris < 0 || m->ntris > 0x0fffff00LL) return -fail(RT_ERR_ARG, "bad triangle count (max 2^28 per mesh)");
   if (m->ntris > 0 && (!m->p1 || !m->p2 || !m->p3)) return -fail(RT_ERR_ARG, "null vertex array");
   bool has_n = m->n1 || m->n2 || m->n3;
   if (has_n && !(m->n1 && m->n2 && m->n3))
@@ -425,7 +612,11 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     M.root = (int32_t)nodes.size();
     M.tri_base = (int32_t)tris.size();
     M.ntris = (int32_t)h.ntris;
-    M.pad[0] = M.pad[1] = 0;
+    for (int a = 0; a < 3; a++) {
+      M.lo[a] = br.lo[a];
+      M.hi[a] = br.hi[a];
+    }
+    M.scale = br.scale;
     int32_t node_base = (int32_t)nodes.size();
     for (DNode N : br.nodes) {
       if (N.c0 >= 0) N.c0 += node_base;
@@ -483,10 +674,10 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   s->d.n_meshes = (int32_t)meshes.size();
   s->d.n_lights = (int32_t)s->lights.size();
   void* pc = nullptr;
-  HIP_TRY(hipMalloc(&pc, N_COUNTERS * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(&pc, (N_COUNTERS + 1) * sizeof(unsigned long long)));
   s->allocs.push_back(pc);
   s->d_counters = static_cast<unsigned long long*>(pc);
-  HIP_TRY(hipMemset(pc, 0, N_COUNTERS * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(pc, 0, (N_COUNTERS + 1) * sizeof(unsigned long long)));
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
 
@@ -534,14 +725,85 @@ static int camera_to_device(const rt_camera* c, DCamera& d) {
   return RT_OK;
 }
 
+static int wf_ensure(void** p, size_t* cap, size_t need, size_t elem) {
+  if (need <= *cap) return RT_OK;
+  if (*p) HIP_TRY(hipFree(*p));
+  *p = nullptr;
+  *cap = 0;
+  size_t want = need + need / 8 + 1024;
+  HIP_TRY(hipMalloc(p, want * elem));
+  *cap = want;
+  return RT_OK;
+}
+
+static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, int64_t ntiles,
+                            int depth, double* d_f64, uint8_t* d_u8, hipStream_t st, bool stats) {
+  if (!s->wf_counts) {
+    HIP_TRY(hipMalloc(&s->wf_counts, (MAX_DEPTH + 2) * sizeof(unsigned int)));
+    HIP_TRY(hipHostMalloc(&s->wf_counts_host, (MAX_DEPTH + 2) * sizeof(unsigned int)));
+  }
+  HIP_TRY(hipMemsetAsync(s->wf_counts, 0, (MAX_DEPTH + 2) * sizeof(unsigned int), st));
+  long long n = ntiles * (RT_TILE * RT_TILE);
+  long long level_n[MAX_DEPTH + 1];
+  int levels = 0;
+  int rc;
+  for (int l = 0; l < depth; l++) {
+    bool spawn = (l + 1 < depth);
+    if ((rc = wf_ensure(&s->wf_nodes[l], &s->wf_node_cap[l], (size_t)n, sizeof(WfNode)))) return rc;
+    if (spawn) {
+      if (2 * n > 0xfffffff0LL) return fail(RT_ERR_UNSUPPORTED, "ray queue exceeds 2^32 entries");
+      if ((rc = wf_ensure(&s->wf_tasks[l + 1], &s->wf_task_cap[l + 1], (size_t)(2 * n), sizeof(WfTask))))
+        return rc;
+    }
+    dim3 grid((unsigned)((n + WF_BLOCK - 1) / WF_BLOCK)), block(WF_BLOCK);
+    const WfTask* tin = static_cast<const WfTask*>(s->wf_tasks[l]);
+    WfNode* nodes = static_cast<WfNode*>(s->wf_nodes[l]);
+    WfTask* tnext = spawn ? static_cast<WfTask*>(s->wf_tasks[l + 1]) : nullptr;
+    unsigned int cap = spawn ? (unsigned int)std::min<size_t>(s->wf_task_cap[l + 1], 0xffffffffu) : 0u;
+    unsigned int* cnt_next = s->wf_counts + l + 1;
+#define WF_LAUNCH(ST, PR)                                                                       \
+  hipLaunchKernelGGL((k_wf_level<ST, PR>), grid, block, 0, st, s->d, dc, pm, tin, n, nodes, tnext, \
+                     cnt_next, cap, spawn ? 1 : 0, s->d_counters)
+    if (l == 0) {
+      if (stats) WF_LAUNCH(true, true); else WF_LAUNCH(false, true);
+    } else {
+      if (stats) WF_LAUNCH(true, false); else WF_LAUNCH(false, false);
+    }
+#undef WF_LAUNCH
+    HIP_TRY(hipGetLastError());
+    s->launches++;
+    level_n[l] = n;
+    levels = l + 1;
+    if (!spawn) break;
+    HIP_TRY(hipMemcpyAsync(s->wf_counts_host + l + 1, cnt_next, sizeof(unsigned int),
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    n = s->wf_counts_host[l + 1];
+    if (n == 0) break;
+  }
+  for (int l = levels - 1; l >= 0; l--) {
+    long long m = level_n[l];
+    dim3 block(256), grid((unsigned)((m + 255) / 256));
+    const WfNode* nodes = static_cast<const WfNode*>(s->wf_nodes[l]);
+    if (l == 0)
+      hipLaunchKernelGGL(k_wf_combine<true>, grid, block, 0, st, nodes, m, (WfNode*)nullptr, d_f64, d_u8);
+    else
+      hipLaunchKernelGGL(k_wf_combine<false>, grid, block, 0, st, nodes, m,
+                         static_cast<WfNode*>(s->wf_nodes[l - 1]), d_f64, d_u8);
+    HIP_TRY(hipGetLastError());
+    s->launches++;
+  }
+  return RT_OK;
+}
+
 int rt_render_device(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline,
                      int tile_first, int tile_step, double* d_rgb_f64, uint8_t* d_rgb_u8,
                      void* hip_stream, int want_stats) {
   if (!s || !cam) return fail(RT_ERR_ARG, "null argument");
   if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
   if (mode != RT_MODE_F64_PARITY) return fail(RT_ERR_UNSUPPORTED, "only RT_MODE_F64_PARITY is built");
-  if (pipeline != RT_PIPELINE_MEGAKERNEL)
-    return fail(RT_ERR_UNSUPPORTED, "only RT_PIPELINE_MEGAKERNEL is built");
+  if (pipeline != RT_PIPELINE_MEGAKERNEL && pipeline != RT_PIPELINE_WAVEFRONT)
+    return fail(RT_ERR_ARG, "unknown pipeline");
   if (depth < 0 || depth > MAX_DEPTH) return fail(RT_ERR_ARG, "depth out of range (0..8)");
   if (!d_rgb_f64 && !d_rgb_u8) return fail(RT_ERR_ARG, "no output buffer");
   DCamera dc;
@@ -557,10 +819,13 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, int depth, int mode, int
   pm.tiles_x = (cam->hsize + RT_TILE - 1) / RT_TILE;
   pm.tile_first = tile_first;
   pm.tile_step = tile_step;
-  if (want_stats) HIP_TRY(hipMemsetAsync(s->d_counters, 0, N_COUNTERS * sizeof(unsigned long long), st));
+  if (want_stats) HIP_TRY(hipMemsetAsync(s->d_counters, 0, (N_COUNTERS + 1) * sizeof(unsigned long long), st));
   HIP_TRY(hipEventRecord(s->ev0, st));
   s->launches = 0;
-  if (ntiles > 0) {
+  if (ntiles > 0 && pipeline == RT_PIPELINE_WAVEFRONT && depth > 0) {
+    rc = render_wavefront(s, dc, pm, ntiles, depth, d_rgb_f64, d_rgb_u8, st, want_stats != 0);
+    if (rc) return rc;
+  } else if (ntiles > 0) {
     constexpr int PATCHES = (RT_TILE / 8) * (RT_TILE / 8);
     dim3 grid((unsigned)(ntiles * PATCHES)), block(64);
     if (want_stats)
@@ -588,8 +853,9 @@ int rt_render_stats(rt_scene* s, rt_stats* st) {
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     st->kernel_ms = ms;
   }
-  unsigned long long c[N_COUNTERS];
+  unsigned long long c[N_COUNTERS + 1];
   HIP_TRY(hipMemcpy(c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+  st->max_nodes_per_query = c[N_COUNTERS];
   st->rays_primary = c[0];
   st->rays_shadow = c[1];
   st->rays_reflect = c[2];

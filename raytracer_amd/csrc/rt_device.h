@@ -284,18 +284,120 @@ __device__ __forceinline__ Ray ray_to_prim(const DScene& S, const DPrim& P, cons
 }
 
 // ---------------------------------------------------------------------------------------
-// Ray / padded-box slab test.  Returns the parametric interval of the infinite line.
-// Boxes are padded at build time, so the few-ulp error of (lo-o)*inv never drops a
-// triangle; min/max ignore the NaN of 0*inf (origin exactly on a slab plane of a
-// direction-parallel axis), which then yields an empty interval for a ray that is a
-// whole pad width away from the geometry.
-__device__ __forceinline__ void slab(const double lo[3], const double hi[3], V3 o, V3 inv,
-                                     double& tn, double& tf) {
-  double ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
-  double ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
-  double az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
-  tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
-  tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+// BVH traversal.  The hierarchy only culls; what a triangle test returns is the f64
+// arithmetic of moller_trumbore() above, bit for bit.  Culling itself runs in f32 against
+// 64-byte nodes (both children's boxes, rounded outward from padded f64 boxes) and is made
+// conservative analytically:
+//   * the ray is re-based to where it enters the mesh's root box (f64), so every f32
+//     operand is of the mesh's own magnitude S = max |coordinate|;
+//   * a direction component smaller than 1e-10 of the largest is replaced by that bound:
+//     inside the mesh the culling ray then strays from the true one by < 4e-10 S, far below
+//     the 1e-7 S padding of every box, and 1/d stays finite;
+//   * plane distances are one fma each, t = plane * (1/d) + c, with c pre-biased by
+//     E = 4 * 2^-24 * (S + |o|) * |1/d|, which bounds the rounding of 1/d to f32 and of the
+//     fma; c is rounded away from the interval (down for near planes, up for far planes);
+//   * the query interval (0 or the running predecessor below, the closest hit or the
+//     shadow distance or the trigger above) is converted with outward rounding.
+// A child is skipped only if its (enlarged) interval misses the (enlarged) query interval.
+struct NodeR {
+  float lo0[3], hi0[3], lo1[3], hi1[3];
+  int32_t c0, c1, n0, n1;
+};
+__device__ __forceinline__ NodeR load_node(const DNode* p) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+  float4 a = q[0], b = q[1], c = q[2];
+  int4 m = *reinterpret_cast<const int4*>(q + 3);
+  NodeR r;
+  r.lo0[0] = a.x; r.lo0[1] = a.y; r.lo0[2] = a.z;
+  r.hi0[0] = a.w; r.hi0[1] = b.x; r.hi0[2] = b.y;
+  r.lo1[0] = b.z; r.lo1[1] = b.w; r.lo1[2] = c.x;
+  r.hi1[0] = c.y; r.hi1[1] = c.z; r.hi1[2] = c.w;
+  r.c0 = m.x; r.c1 = m.y; r.n0 = m.z; r.n1 = m.w;
+  return r;
+}
+__device__ __forceinline__ DTri load_tri(const DTri* p) {
+  const double2* q = reinterpret_cast<const double2*>(p);
+  double2 a = q[0], b = q[1], c = q[2], d = q[3];
+  uint4 e = *reinterpret_cast<const uint4*>(q + 4);
+  DTri t;
+  t.p1[0] = a.x; t.p1[1] = a.y; t.p1[2] = b.x;
+  t.e1[0] = b.y; t.e1[1] = c.x; t.e1[2] = c.y;
+  t.e2[0] = d.x; t.e2[1] = d.y;
+  t.e2[2] = __hiloint2double((int)e.y, (int)e.x);
+  t.orig = e.z;
+  t.smooth = e.w;
+  return t;
+}
+
+__device__ __forceinline__ float f32_down(double x) {  // largest float <= x
+  float f = (float)x;
+  if ((double)f > x) f = __uint_as_float(__float_as_uint(f) + ((f > 0.0f) ? -1 : 1));
+  if (f == 0.0f && x < 0.0) f = -1.401298464e-45f;
+  return f;
+}
+__device__ __forceinline__ float f32_up(double x) { return -f32_down(-x); }
+
+struct CullRay {
+  float id[3];  // 1/d of the culling ray
+  float cn[3];  // near-plane offsets, biased down
+  float cf[3];  // far-plane offsets, biased up
+  bool neg[3];  // direction negative: the near plane of that axis is `hi`
+  double t_base;
+  bool miss;  // the ray does not touch the mesh's root box at all
+};
+
+// lo/hi: the mesh's padded root box; want_negative: the query reaches behind the origin.
+__device__ inline CullRay make_cull_ray(const DMesh& M, const Ray& lr, bool want_negative) {
+  CullRay c;
+  const double o[3] = {lr.o.x, lr.o.y, lr.o.z};
+  const double d[3] = {lr.d.x, lr.d.y, lr.d.z};
+  // where the true ray crosses the root box (f64; NaN from 0*inf is ignored by fmin/fmax)
+  double tin = -RT_INF, tout = RT_INF;
+  for (int a = 0; a < 3; a++) {
+    double inv = 1.0 / d[a];
+    double t0 = (M.lo[a] - o[a]) * inv, t1 = (M.hi[a] - o[a]) * inv;
+    tin = fmax(tin, fmin(t0, t1));
+    tout = fmin(tout, fmax(t0, t1));
+  }
+  c.miss = !(tin <= tout) || (!want_negative && tout < 0.0);
+  double tb = tin;
+  if (!want_negative && !(tb > 0.0)) tb = 0.0;
+  if (!(tb > -1e300 && tb < 1e300)) tb = 0.0;
+  c.t_base = tb;
+  double dmax = fmax(fmax(fabs(d[0]), fabs(d[1])), fabs(d[2]));
+  bool degenerate = !(dmax > 0.0 && dmax < 1e300);
+  for (int a = 0; a < 3; a++) {
+    double oa = o[a] + d[a] * tb;  // re-based origin
+    double da = d[a];
+    double dmin = dmax * 1e-10;
+    if (!(fabs(da) >= dmin)) da = (da < 0.0) ? -dmin : dmin;
+    double inv = 1.0 / da;
+    double oid = oa * inv;
+    double E = (4.0 * 5.9604644775390625e-08) * (M.scale + fabs(oa)) * fabs(inv);
+    c.neg[a] = da < 0.0;
+    if (degenerate || !(fabs(oid) < 1e30) || !(fabs(inv) < 1e30)) {
+      c.id[a] = 0.0f;  // no culling on this axis
+      c.cn[a] = -__builtin_huge_valf();
+      c.cf[a] = __builtin_huge_valf();
+    } else {
+      c.id[a] = (float)inv;
+      c.cn[a] = f32_down(-oid - E);
+      c.cf[a] = f32_up(-oid + E);
+    }
+  }
+  return c;
+}
+
+// Enlarged parametric interval (in t - t_base) of one child box.
+__device__ __forceinline__ void slab32(const float lo[3], const float hi[3], const CullRay& c,
+                                       float& tn, float& tf) {
+  float nx = c.neg[0] ? hi[0] : lo[0], fx = c.neg[0] ? lo[0] : hi[0];
+  float ny = c.neg[1] ? hi[1] : lo[1], fy = c.neg[1] ? lo[1] : hi[1];
+  float nz = c.neg[2] ? hi[2] : lo[2], fz = c.neg[2] ? lo[2] : hi[2];
+  tn = fmaxf(fmaxf(__fmaf_rn(nx, c.id[0], c.cn[0]), __fmaf_rn(ny, c.id[1], c.cn[1])),
+             __fmaf_rn(nz, c.id[2], c.cn[2]));
+  tf = fminf(fminf(__fmaf_rn(fx, c.id[0], c.cf[0]), __fmaf_rn(fy, c.id[1], c.cf[1])),
+             __fmaf_rn(fz, c.id[2], c.cf[2]));
 }
 
 struct HitRec {
@@ -306,200 +408,25 @@ struct HitRec {
   int32_t tri;  // global record index in the triangle table
 };
 
+// Traversal stack of one lane: the first LDS_STACK entries live in LDS (entry i of lane l at
+// lds[i*stride + l]: lanes of a wave touch distinct banks whatever their depths), deeper
+// entries spill to a private array that well-built trees never reach.
 constexpr int STACK_MAX = 64;
-
-// hit() of intersect.rs:125-139 over the list of world.rs:22-32: smallest t > 0, the
-// earliest leaf among equal t.
-template <bool STATS>
-__device__ inline bool trace_closest(const DScene& S, const Ray& ray, HitRec& h, Counters& cnt) {
-  double best_t = RT_INF;
-  uint32_t best_order = 0xffffffffu;
-  h.prim = -1;
-  h.mesh = -1;
-  h.tri = -1;
-  h.u = 0.0;
-  h.v = 0.0;
-  bool found = false;
-  for (int p = 0; p < S.n_prims; p++) {
-    const DPrim& P = S.prims[p];
-    Ray lr = ray_to_prim(S, P, ray);
-    double ts[4];
-    int n = prim_local_intersect(P, lr, ts);
-    if (STATS) cnt.prim_tests++;
-    for (int k = 0; k < n; k++) {
-      double t = ts[k];
-      if (t > 0.0 && (t < best_t || (t == best_t && P.order < best_order))) {
-        best_t = t;
-        best_order = P.order;
-        h.prim = p;
-        found = true;
-      }
-    }
+constexpr int LDS_STACK = 24;
+struct TravStack {
+  int* lds;
+  int stride;
+  int spill[STACK_MAX - LDS_STACK];
+  __device__ __forceinline__ void put(int i, int v) {
+    if (i < LDS_STACK)
+      lds[i * stride] = v;
+    else
+      spill[i - LDS_STACK] = v;
   }
-  int stack[STACK_MAX];
-  for (int m = 0; m < S.n_meshes; m++) {
-    const DMesh& M = S.meshes[m];
-    Ray lr = ray_to_group(S, M.group, ray);
-    if (STATS) cnt.inst_entries++;
-    V3 inv = v3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
-    const DTri* tris = S.tris + M.tri_base;
-    int sp = 0;
-    int node = M.root;
-    while (true) {
-      const DNode& N = S.nodes[node];
-      if (STATS) cnt.nodes_visited++;
-      double tn0, tf0, tn1, tf1;
-      slab(N.lo0, N.hi0, lr.o, inv, tn0, tf0);
-      slab(N.lo1, N.hi1, lr.o, inv, tn1, tf1);
-      bool h0 = (tn0 <= tf0) && (tf0 >= 0.0) && (tn0 <= best_t) && (N.n0 != 0 || N.c0 >= 0);
-      bool h1 = (tn1 <= tf1) && (tf1 >= 0.0) && (tn1 <= best_t) && (N.n1 != 0 || N.c1 >= 0);
-      int next0 = -1, next1 = -1;
-      if (h0) {
-        if (N.c0 >= 0) {
-          next0 = N.c0;
-        } else {
-          int first = -(N.c0 + 1);
-          for (int k = 0; k < N.n0; k++) {
-            const DTri& T = tris[first + k];
-            double t, u, v;
-            if (STATS) cnt.tri_tests++;
-            if (moller_trumbore(T, lr, t, u, v)) {
-              uint32_t ord = M.order_base + T.orig;
-              if (t > 0.0 && (t < best_t || (t == best_t && ord < best_order))) {
-                best_t = t;
-                best_order = ord;
-                h.prim = -1;
-                h.mesh = m;
-                h.tri = M.tri_base + first + k;
-                h.u = u;
-                h.v = v;
-                found = true;
-              }
-            }
-          }
-        }
-      }
-      if (h1) {
-        if (N.c1 >= 0) {
-          next1 = N.c1;
-        } else {
-          int first = -(N.c1 + 1);
-          for (int k = 0; k < N.n1; k++) {
-            const DTri& T = tris[first + k];
-            double t, u, v;
-            if (STATS) cnt.tri_tests++;
-            if (moller_trumbore(T, lr, t, u, v)) {
-              uint32_t ord = M.order_base + T.orig;
-              if (t > 0.0 && (t < best_t || (t == best_t && ord < best_order))) {
-                best_t = t;
-                best_order = ord;
-                h.prim = -1;
-                h.mesh = m;
-                h.tri = M.tri_base + first + k;
-                h.u = u;
-                h.v = v;
-                found = true;
-              }
-            }
-          }
-        }
-      }
-      if (next0 >= 0 && next1 >= 0) {
-        // nearer child first; the other waits on the stack
-        if (tn1 < tn0) {
-          int s = next0;
-          next0 = next1;
-          next1 = s;
-        }
-        if (sp < STACK_MAX) stack[sp++] = next1;
-        node = next0;
-      } else if (next0 >= 0) {
-        node = next0;
-      } else if (next1 >= 0) {
-        node = next1;
-      } else {
-        if (sp == 0) break;
-        node = stack[--sp];
-      }
-    }
+  __device__ __forceinline__ int get(int i) const {
+    return i < LDS_STACK ? lds[i * stride] : spill[i - LDS_STACK];
   }
-  h.t = best_t;
-  h.order = best_order;
-  return found;
-}
-
-// is_shadowed (world.rs:116-134): the nearest positive hit is closer than `distance`
-// exactly when some intersection has 0 < t < distance.
-template <bool STATS>
-__device__ inline bool trace_any(const DScene& S, const Ray& ray, double distance, Counters& cnt) {
-  for (int p = 0; p < S.n_prims; p++) {
-    const DPrim& P = S.prims[p];
-    Ray lr = ray_to_prim(S, P, ray);
-    double ts[4];
-    int n = prim_local_intersect(P, lr, ts);
-    if (STATS) cnt.prim_tests++;
-    for (int k = 0; k < n; k++)
-      if (ts[k] > 0.0 && ts[k] < distance) return true;
-  }
-  int stack[STACK_MAX];
-  for (int m = 0; m < S.n_meshes; m++) {
-    const DMesh& M = S.meshes[m];
-    Ray lr = ray_to_group(S, M.group, ray);
-    if (STATS) cnt.inst_entries++;
-    V3 inv = v3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
-    const DTri* tris = S.tris + M.tri_base;
-    int sp = 0;
-    int node = M.root;
-    while (true) {
-      const DNode& N = S.nodes[node];
-      if (STATS) cnt.nodes_visited++;
-      double tn0, tf0, tn1, tf1;
-      slab(N.lo0, N.hi0, lr.o, inv, tn0, tf0);
-      slab(N.lo1, N.hi1, lr.o, inv, tn1, tf1);
-      bool h0 = (tn0 <= tf0) && (tf0 >= 0.0) && (tn0 <= distance) && (N.n0 != 0 || N.c0 >= 0);
-      bool h1 = (tn1 <= tf1) && (tf1 >= 0.0) && (tn1 <= distance) && (N.n1 != 0 || N.c1 >= 0);
-      int next0 = -1, next1 = -1;
-      if (h0) {
-        if (N.c0 >= 0) {
-          next0 = N.c0;
-        } else {
-          int first = -(N.c0 + 1);
-          for (int k = 0; k < N.n0; k++) {
-            double t, u, v;
-            if (STATS) cnt.tri_tests++;
-            if (moller_trumbore(tris[first + k], lr, t, u, v) && t > 0.0 && t < distance)
-              return true;
-          }
-        }
-      }
-      if (h1) {
-        if (N.c1 >= 0) {
-          next1 = N.c1;
-        } else {
-          int first = -(N.c1 + 1);
-          for (int k = 0; k < N.n1; k++) {
-            double t, u, v;
-            if (STATS) cnt.tri_tests++;
-            if (moller_trumbore(tris[first + k], lr, t, u, v) && t > 0.0 && t < distance)
-              return true;
-          }
-        }
-      }
-      if (next0 >= 0 && next1 >= 0) {
-        if (sp < STACK_MAX) stack[sp++] = next1;
-        node = next0;
-      } else if (next0 >= 0) {
-        node = next0;
-      } else if (next1 >= 0) {
-        node = next1;
-      } else {
-        if (sp == 0) break;
-        node = stack[--sp];
-      }
-    }
-  }
-  return false;
-}
+};
 
 // Sort key of one entry of the reference's intersection list: ascending t, ties by leaf
 // order, then by emission order inside one shape (stable sorts, group.rs:69, world.rs:29).
@@ -515,92 +442,210 @@ __device__ __forceinline__ bool key_less(const Key& a, const Key& b) {
   return a.emit < b.emit;
 }
 
+enum { Q_CLOSEST = 0, Q_ANY = 1, Q_PRED = 2 };
+
+// State of one query over the meshes.
+//   Q_CLOSEST: smallest t > 0, ties by leaf order  (hi = best t so far)
+//   Q_ANY:     is there 0 < t < hi
+//   Q_PRED:    largest key below K over the whole line (t may be negative)
+struct Query {
+  double hi;          // upper end of the t interval of interest
+  uint32_t hi_order;  // Q_CLOSEST: leaf order of the best hit; Q_PRED: K.order
+  Key best;           // Q_PRED: best predecessor so far
+  bool found;
+  int32_t mesh, tri;
+  double u, v;
+};
+
+template <int MODE, bool STATS>
+__device__ __forceinline__ bool test_leaf(const DMesh& M, int m, const DTri* tris, int first, int count,
+                                          const Ray& lr, Query& q, Counters& cnt) {
+  for (int k = 0; k < count; k++) {
+    const DTri T = load_tri(tris + first + k);
+    double t, u, v;
+    if (STATS) cnt.tri_tests++;
+    if (!moller_trumbore(T, lr, t, u, v)) continue;
+    uint32_t ord = M.order_base + T.orig;
+    if (MODE == Q_CLOSEST) {
+      if (t > 0.0 && (t < q.hi || (t == q.hi && ord < q.hi_order))) {
+        q.hi = t;
+        q.hi_order = ord;
+        q.mesh = m;
+        q.tri = M.tri_base + first + k;
+        q.u = u;
+        q.v = v;
+        q.found = true;
+      }
+    } else if (MODE == Q_ANY) {
+      if (t > 0.0 && t < q.hi) return true;
+    } else {
+      Key c{t, ord, 0};
+      Key K{q.hi, q.hi_order, 0};
+      if (key_less(c, K) && (!q.found || key_less(q.best, c))) {
+        q.best = c;
+        q.mesh = m;
+        q.found = true;
+      }
+    }
+  }
+  return false;
+}
+
+// Walks every mesh.  Returns true as soon as a Q_ANY query is satisfied.
+template <int MODE, bool STATS>
+__device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q, Counters& cnt,
+                                       TravStack& st) {
+  for (int m = 0; m < S.n_meshes; m++) {
+    const DMesh& M = S.meshes[m];
+    Ray lr = ray_to_group(S, M.group, ray);
+    if (STATS) cnt.inst_entries++;
+    CullRay c = make_cull_ray(M, lr, MODE == Q_PRED);
+    if (c.miss) continue;
+    const DTri* tris = S.tris + M.tri_base;
+    // query interval in t - t_base, rounded outward
+    float qlo, qhi;
+    if (MODE == Q_PRED) {
+      qlo = q.found ? f32_down(q.best.t - c.t_base) : -__builtin_huge_valf();
+      qhi = f32_up(q.hi - c.t_base);
+    } else {
+      qlo = f32_down(0.0 - c.t_base);
+      qhi = (q.hi < 1e300) ? f32_up(q.hi - c.t_base) : __builtin_huge_valf();
+    }
+    // "while-while" traversal: every lane first descends inner nodes until it holds a leaf
+    // (or runs out), then the lanes test their leaves' triangles together, so that node
+    // fetches and triangle tests each run with as many active lanes as possible.  Stack and
+    // `cur` hold inner node indices (>= 0) or leaf codes (<= -2); -1 means nothing left.
+    int sp = 0;
+    int cur = M.root;
+    unsigned long long visited = 0;
+    while (cur != -1) {
+      while (cur >= 0) {
+        const NodeR N = load_node(S.nodes + cur);
+        if (STATS) {
+          cnt.nodes_visited++;
+          visited++;
+          if (visited > cnt.max_nodes) cnt.max_nodes = visited;
+        }
+        float tn0, tf0, tn1, tf1;
+        slab32(N.lo0, N.hi0, c, tn0, tf0);
+        slab32(N.lo1, N.hi1, c, tn1, tf1);
+        bool h0 = fmaxf(tn0, qlo) <= fminf(tf0, qhi);
+        bool h1 = fmaxf(tn1, qlo) <= fminf(tf1, qhi);
+        if (h0 && h1) {
+          // Q_CLOSEST / Q_ANY: nearer child first; Q_PRED: the child reaching further up first
+          bool second_first = (MODE == Q_PRED) ? (tf1 > tf0) : (tn1 < tn0);
+          int near = second_first ? N.c1 : N.c0;
+          int far = second_first ? N.c0 : N.c1;
+          if (sp < STACK_MAX) st.put(sp++, far);
+          cur = near;
+        } else if (h0) {
+          cur = N.c0;
+        } else if (h1) {
+          cur = N.c1;
+        } else {
+          cur = sp ? st.get(--sp) : -1;
+        }
+      }
+      if (cur != -1) {
+        int code = -2 - cur;
+        if (test_leaf<MODE, STATS>(M, m, tris, code >> 3, code & 7, lr, q, cnt)) return true;
+        // a leaf may have tightened the interval
+        if (MODE == Q_CLOSEST) {
+          if (q.hi < 1e300) qhi = f32_up(q.hi - c.t_base);
+        } else if (MODE == Q_PRED) {
+          if (q.found) qlo = f32_down(q.best.t - c.t_base);
+        }
+        cur = sp ? st.get(--sp) : -1;
+      }
+    }
+  }
+  return false;
+}
+
+// hit() of intersect.rs:125-139 over the list of world.rs:22-32: smallest t > 0, the
+// earliest leaf among equal t.
+template <bool STATS>
+__device__ inline bool trace_closest(const DScene& S, const Ray& ray, HitRec& h, Counters& cnt,
+                                     TravStack& st) {
+  Query q;
+  q.hi = RT_INF;
+  q.hi_order = 0xffffffffu;
+  q.found = false;
+  q.mesh = -1;
+  q.tri = -1;
+  q.u = 0.0;
+  q.v = 0.0;
+  int prim = -1;
+  for (int p = 0; p < S.n_prims; p++) {
+    const DPrim& P = S.prims[p];
+    Ray lr = ray_to_prim(S, P, ray);
+    double ts[4];
+    int n = prim_local_intersect(P, lr, ts);
+    if (STATS) cnt.prim_tests++;
+    for (int k = 0; k < n; k++) {
+      double t = ts[k];
+      if (t > 0.0 && (t < q.hi || (t == q.hi && P.order < q.hi_order))) {
+        q.hi = t;
+        q.hi_order = P.order;
+        prim = p;
+        q.found = true;
+      }
+    }
+  }
+  int prim_before = q.mesh;  // stays -1 unless a triangle wins
+  traverse_meshes<Q_CLOSEST, STATS>(S, ray, q, cnt, st);
+  (void)prim_before;
+  h.t = q.hi;
+  h.order = q.hi_order;
+  h.u = q.u;
+  h.v = q.v;
+  h.mesh = q.mesh;
+  h.tri = q.tri;
+  h.prim = (q.mesh >= 0) ? -1 : prim;
+  return q.found;
+}
+
+// is_shadowed (world.rs:116-134): the nearest positive hit is closer than `distance`
+// exactly when some intersection has 0 < t < distance.
+template <bool STATS>
+__device__ inline bool trace_any(const DScene& S, const Ray& ray, double distance, Counters& cnt,
+                                 TravStack& st) {
+  for (int p = 0; p < S.n_prims; p++) {
+    const DPrim& P = S.prims[p];
+    Ray lr = ray_to_prim(S, P, ray);
+    double ts[4];
+    int n = prim_local_intersect(P, lr, ts);
+    if (STATS) cnt.prim_tests++;
+    for (int k = 0; k < n; k++)
+      if (ts[k] > 0.0 && ts[k] < distance) return true;
+  }
+  Query q;
+  q.hi = distance;
+  q.hi_order = 0;
+  q.found = false;
+  q.mesh = -1;
+  q.tri = -1;
+  return traverse_meshes<Q_ANY, STATS>(S, ray, q, cnt, st);
+}
+
 // Largest key below K among all triangle intersections of the infinite line (t may be
 // negative).  Every triangle is its own shape with at most one entry, so this is the last
 // triangle still "open" when the containers walk of intersect.rs:188-222 reaches K.
 template <bool STATS>
 __device__ inline bool tri_predecessor(const DScene& S, const Ray& ray, const Key& K, Key& best,
-                                       int& best_mesh, Counters& cnt) {
-  bool found = false;
-  int stack[STACK_MAX];
-  for (int m = 0; m < S.n_meshes; m++) {
-    const DMesh& M = S.meshes[m];
-    Ray lr = ray_to_group(S, M.group, ray);
-    if (STATS) cnt.inst_entries++;
-    V3 inv = v3(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
-    const DTri* tris = S.tris + M.tri_base;
-    int sp = 0;
-    int node = M.root;
-    while (true) {
-      const DNode& N = S.nodes[node];
-      if (STATS) cnt.nodes_visited++;
-      double tn0, tf0, tn1, tf1;
-      slab(N.lo0, N.hi0, lr.o, inv, tn0, tf0);
-      slab(N.lo1, N.hi1, lr.o, inv, tn1, tf1);
-      double floor_t = found ? best.t : -RT_INF;
-      bool h0 = (tn0 <= tf0) && (tn0 <= K.t) && (tf0 >= floor_t) && (N.n0 != 0 || N.c0 >= 0);
-      bool h1 = (tn1 <= tf1) && (tn1 <= K.t) && (tf1 >= floor_t) && (N.n1 != 0 || N.c1 >= 0);
-      int next0 = -1, next1 = -1;
-      if (h0) {
-        if (N.c0 >= 0) {
-          next0 = N.c0;
-        } else {
-          int first = -(N.c0 + 1);
-          for (int k = 0; k < N.n0; k++) {
-            const DTri& T = tris[first + k];
-            double t, u, v;
-            if (STATS) cnt.tri_tests++;
-            if (moller_trumbore(T, lr, t, u, v)) {
-              Key c{t, M.order_base + T.orig, 0};
-              if (key_less(c, K) && (!found || key_less(best, c))) {
-                best = c;
-                best_mesh = m;
-                found = true;
-              }
-            }
-          }
-        }
-      }
-      if (h1) {
-        if (N.c1 >= 0) {
-          next1 = N.c1;
-        } else {
-          int first = -(N.c1 + 1);
-          for (int k = 0; k < N.n1; k++) {
-            const DTri& T = tris[first + k];
-            double t, u, v;
-            if (STATS) cnt.tri_tests++;
-            if (moller_trumbore(T, lr, t, u, v)) {
-              Key c{t, M.order_base + T.orig, 0};
-              if (key_less(c, K) && (!found || key_less(best, c))) {
-                best = c;
-                best_mesh = m;
-                found = true;
-              }
-            }
-          }
-        }
-      }
-      if (next0 >= 0 && next1 >= 0) {
-        // the child reaching further towards K first
-        if (tf1 > tf0) {
-          int s = next0;
-          next0 = next1;
-          next1 = s;
-        }
-        if (sp < STACK_MAX) stack[sp++] = next1;
-        node = next0;
-      } else if (next0 >= 0) {
-        node = next0;
-      } else if (next1 >= 0) {
-        node = next1;
-      } else {
-        if (sp == 0) break;
-        node = stack[--sp];
-      }
-    }
+                                       int& best_mesh, Counters& cnt, TravStack& st) {
+  Query q;
+  q.hi = K.t;
+  q.hi_order = K.order;
+  q.found = false;
+  q.mesh = -1;
+  q.tri = -1;
+  traverse_meshes<Q_PRED, STATS>(S, ray, q, cnt, st);
+  if (q.found) {
+    best = q.best;
+    best_mesh = q.mesh;
   }
-  return found;
+  return q.found;
 }
 
 // n1/n2 of prepare_computations (intersect.rs:188-222) without the list.
@@ -612,7 +657,8 @@ __device__ inline bool tri_predecessor(const DScene& S, const Ray& ray, const Ke
 // latest entry has the largest key.
 template <bool STATS>
 __device__ inline void containers_n1_n2(const DScene& S, const Ray& ray, const HitRec& h,
-                                        double own_ri, double& n1, double& n2, Counters& cnt) {
+                                        double own_ri, double& n1, double& n2, Counters& cnt,
+                                        TravStack& st) {
   if (STATS) cnt.pred_queries++;
   Key K{h.t, h.order, 0};
   if (h.prim >= 0) {
@@ -669,7 +715,7 @@ __device__ inline void containers_n1_n2(const DScene& S, const Ray& ray, const H
   if (S.n_meshes > 0) {
     Key tb{0.0, 0u, 0};
     int tm = -1;
-    if (tri_predecessor<STATS>(S, ray, K, tb, tm, cnt)) {
+    if (tri_predecessor<STATS>(S, ray, K, tb, tm, cnt, st)) {
       double ri = S.mats[S.meshes[tm].material].refractive_index;
       if (!have_all || key_less(best_all, tb)) {
         best_all = tb;
@@ -736,7 +782,7 @@ struct ShadeOut {
 // set-up of reflected_color / refracted_color / schlick (world.rs:78-165).
 template <bool STATS>
 __device__ inline void shade_hit_local(const DScene& S, const Ray& ray, const HitRec& h,
-                                       ShadeOut& o, Counters& cnt) {
+                                       ShadeOut& o, Counters& cnt, TravStack& st) {
   if (STATS) cnt.shade_calls++;
   V3 point = ray_at(ray, h.t);
   V3 normal;
@@ -805,7 +851,7 @@ __device__ inline void shade_hit_local(const DScene& S, const Ray& ray, const Hi
     V3 direction = v3(v.x / distance, v.y / distance, v.z / distance);
     Ray sr = {over, direction};
     if (STATS) cnt.rays_shadow++;
-    bool shadow = trace_any<STATS>(S, sr, distance, cnt);
+    bool shadow = trace_any<STATS>(S, sr, distance, cnt, st);
     // lighting
     C3 eff = {pc.r * L.intensity[0], pc.g * L.intensity[1], pc.b * L.intensity[2]};
     V3 lightv = direction;  // normalize(light.position - position): the same expression
@@ -839,7 +885,7 @@ __device__ inline void shade_hit_local(const DScene& S, const Ray& ray, const Hi
   bool want_refract = !feq(M.transparency, 0.0);  // world.rs:90
   if (want_refract || o.use_schlick) {
     double n1, n2;
-    containers_n1_n2<STATS>(S, ray, h, M.refractive_index, n1, n2, cnt);
+    containers_n1_n2<STATS>(S, ray, h, M.refractive_index, n1, n2, cnt, st);
     o.n1 = n1;
     o.n2 = n2;
     if (want_refract) {  // world.rs:94-112
@@ -903,7 +949,7 @@ constexpr int MAX_DEPTH = 8;
 
 // World::color_at(ray, depth) with the recursion unrolled onto an explicit stack.
 template <bool STATS>
-__device__ inline C3 color_at(const DScene& S, Ray ray, int depth, Counters& cnt) {
+__device__ inline C3 color_at(const DScene& S, Ray ray, int depth, Counters& cnt, TravStack& st) {
   Frame frames[MAX_DEPTH];
   int level = 0;
   C3 ret = {0.0, 0.0, 0.0};
@@ -913,11 +959,11 @@ __device__ inline C3 color_at(const DScene& S, Ray ray, int depth, Counters& cnt
   while (true) {
     // ---- enter color_at(ray, remaining), remaining >= 1 or the top-level call
     HitRec h;
-    bool found = trace_closest<STATS>(S, ray, h, cnt);
+    bool found = trace_closest<STATS>(S, ray, h, cnt, st);
     bool returning = true;
     if (found && remaining > 0) {
       ShadeOut so;
-      shade_hit_local<STATS>(S, ray, h, so, cnt);
+      shade_hit_local<STATS>(S, ray, h, so, cnt, st);
       {
         Frame& F = frames[level];
         F.surface = so.surface;

@@ -22,12 +22,13 @@ struct alignas(16) DPrim {
   uint32_t pad[3];
 };
 struct alignas(16) DMesh {
+  double lo[3], hi[3];  // padded bounds of the whole mesh (object space)
+  double scale;         // largest |coordinate| of the mesh
   int32_t group, material;
   uint32_t order_base;  // leaf order of triangle 0
   int32_t root;         // index of the root node in the node table
   int32_t tri_base;     // first record in the triangle table
   int32_t ntris;
-  int32_t pad[2];
 };
 // One triangle as the intersection test reads it: p1, e1 = p2-p1, e2 = p3-p1
 // (triangle.rs:49-50).  80 bytes.
@@ -40,13 +41,13 @@ struct alignas(16) DTri {
 struct alignas(8) DTriN {
   double n[9];
 };
-// Binary BVH node holding the boxes of BOTH children, so one 128-byte fetch decides
-// both.  Child c >= 0: inner node index.  Child c < 0: leaf, first triangle = -(c+1)
-// relative to the mesh's tri_base, count in n0/n1 (0 = empty child).
-struct alignas(128) DNode {
-  double lo0[3], hi0[3], lo1[3], hi1[3];
+// Binary BVH node holding the boxes of BOTH children in f32 (rounded outward from the padded
+// f64 boxes), so one 64-byte fetch decides both.  Child c >= 0: inner node index; c == -1:
+// no child (its box is inverted); c <= -2: leaf, code = -2 - c = (first << 3) | count with
+// `first` relative to the mesh's tri_base and count <= 4 (n0/n1 repeat the counts).
+struct alignas(64) DNode {
+  float lo0[3], hi0[3], lo1[3], hi1[3];
   int32_t c0, c1, n0, n1;
-  int32_t pad[4];
 };
 struct alignas(16) DMaterial {
   double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
@@ -79,7 +80,8 @@ struct DCamera {
 struct Counters {
   unsigned long long rays_primary, rays_shadow, rays_reflect, rays_refract, depth0_skipped,
       pred_queries, nodes_visited, tri_tests, prim_tests, inst_entries, shade_calls;
+  unsigned long long max_nodes;  // not a sum: the longest single traversal (nodes)
 };
-constexpr int N_COUNTERS = 11;
+constexpr int N_COUNTERS = 11;  // summed counters; max_nodes is stored after them
 
 }  // namespace rtd

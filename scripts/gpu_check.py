@@ -7,6 +7,7 @@ import raytracer_amd as rt
 from oracle import oracle as O
 
 scenes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["cover", "pawn", "tea set"]
+PIPE = int(os.environ.get("RT_PIPE", "0"))
 for name in scenes:
     t0 = time.time()
     w = rt.World.example(name)
@@ -14,10 +15,10 @@ for name in scenes:
     w.commit()
     t2 = time.time()
     print(name, "build %.2fs commit %.2fs" % (t1 - t0, t2 - t1), w.info(), flush=True)
-    u8, f64, st = w.render(want_stats=True)
+    u8, f64, st = w.render(want_stats=True, pipeline=PIPE)
     print(" stats", st.as_dict(), flush=True)
-    u8b, _, _ = w.render()
-    u8c, _, st2 = w.render(want_stats=False)
+    u8b, _, _ = w.render(pipeline=PIPE)
+    u8c, _, st2 = w.render(want_stats=False, pipeline=PIPE)
     s = w.stats()
     print(" no-stats kernel_ms %.3f  Mrays/s %.1f" % (s.kernel_ms, st.rays() / s.kernel_ms / 1e3), flush=True)
     gold = O.golden_image(name)
