@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pawn1080", choices=sorted(WORKLOADS))
-    ap.add_argument("--pipeline", default="megakernel", choices=["megakernel", "wavefront"])
+    ap.add_argument("--pipeline", default="wavefront", choices=["megakernel", "wavefront"])
     ap.add_argument("--cpu-pixels", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -98,7 +98,7 @@ def main():
     dev = torch.device("cuda", local_rank if world_size > 1 else 0)
 
     example, hs, vs, ntris, desc = WORKLOADS[args.workload]
-    pipeline = rt.PIPELINE_MEGAKERNEL if args.pipeline == "megakernel" else rt.PIPELINE_WAVEFRONT
+    pipeline = {"megakernel": rt.PIPELINE_MEGAKERNEL, "wavefront": rt.PIPELINE_WAVEFRONT}[args.pipeline]
     w = rt.World.example(example, hs, vs, synthetic_tris=ntris).commit(device=dev.index)
     info = w.info()
     stream = torch.cuda.current_stream().cuda_stream

@@ -54,8 +54,8 @@ enum { RT_SPHERE = 0, RT_PLANE = 1, RT_CUBE = 2, RT_CYLINDER = 3, RT_CONE = 4 };
 enum { RT_SOLID = 0, RT_STRIPE = 1, RT_GRADIENT = 2, RT_RINGS = 3, RT_CHECKERED = 4 };
 /* arithmetic mode of the kernels */
 enum { RT_MODE_F64_PARITY = 0, RT_MODE_F32_FAST = 1 };
-/* kernel organisation: one lane per pixel with an explicit recursion stack, or
- * per-depth ray queues ("wavefront") */
+/* kernel organisation: one lane per pixel with an explicit recursion stack, or per-depth
+ * ray queues with one fused trace+shade kernel per depth ("wavefront") */
 enum { RT_PIPELINE_MEGAKERNEL = 0, RT_PIPELINE_WAVEFRONT = 1 };
 
 /* draw/material.rs:6-15 + the pattern it boxes (patterns.rs).  pattern_inv is the

@@ -23,6 +23,8 @@ GROUP = 7
 SOLID, STRIPE, GRADIENT, RINGS, CHECKERED = range(5)
 MODE_F64_PARITY, MODE_F32_FAST = 0, 1
 PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT = 0, 1
+# pipeline used when a render call does not name one
+DEFAULT_PIPELINE = PIPELINE_WAVEFRONT
 TILE = 32
 
 
@@ -290,9 +292,10 @@ class World:
             raise RtError(self.L.rt_last_error().decode())
         return si.as_dict()
 
-    def render(self, depth=5, mode=MODE_F64_PARITY, pipeline=PIPELINE_MEGAKERNEL, want_f64=False,
+    def render(self, depth=5, mode=MODE_F64_PARITY, pipeline=None, want_f64=False,
                want_stats=False):
         """Returns (u8 HxWx3, f64 HxWx3 or None, Stats or None)."""
+        pipeline = DEFAULT_PIPELINE if pipeline is None else pipeline
         cam = self.camera_abi()
         n = cam.hsize * cam.vsize * 3
         u8 = np.zeros(n, dtype=np.uint8)
@@ -307,9 +310,10 @@ class World:
         return u8.reshape(shape), (f64.reshape(shape) if want_f64 else None), st
 
     def render_device(self, d_u8=None, d_f64=None, stream=None, depth=5, mode=MODE_F64_PARITY,
-                      pipeline=PIPELINE_MEGAKERNEL, tile_first=0, tile_step=1, want_stats=False,
+                      pipeline=None, tile_first=0, tile_step=1, want_stats=False,
                       cam=None):
         """rt_render_device: device pointers (ints), asynchronous on `stream` (a hipStream_t)."""
+        pipeline = DEFAULT_PIPELINE if pipeline is None else pipeline
         cam = cam or self.camera_abi()
         rc = self.L.rt_render_device(self.scene, C.byref(cam), depth, mode, pipeline, tile_first,
                                      tile_step, C.c_void_p(d_f64 or 0), C.c_void_p(d_u8 or 0),

@@ -216,7 +216,7 @@ void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, 
   B.p2 = p2;
   B.p3 = p3;
   B.n = n;
-  B.max_leaf = std::max(1, std::min(max_leaf, 4));
+  B.max_leaf = std::max(1, std::min(max_leaf, 7));
   B.tri_box.resize(n);
   B.cen.resize(3 * n);
   B.idx.resize(n);

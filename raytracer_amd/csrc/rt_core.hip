@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -387,6 +388,7 @@ __global__ void k_wf_combine(const WfNode* nodes, long long n, WfNode* parents, 
   }
 }
 
+
 template <typename T>
 static int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
   *out = nullptr;
@@ -602,7 +604,9 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   for (size_t mi = 0; mi < s->meshes.size(); mi++) {
     const MeshH& h = s->meshes[mi];
     rtb::BuildResult br;
-    rtb::build_sah(h.p1.data(), h.p2.data(), h.p3.data(), h.ntris, 4, br);
+    int max_leaf = 6;
+    if (const char* e = getenv("RT_MAX_LEAF")) max_leaf = atoi(e);
+    rtb::build_sah(h.p1.data(), h.p2.data(), h.p3.data(), h.ntris, max_leaf, br);
     if (br.max_depth >= STACK_MAX - 2)
       return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     DMesh& M = meshes[mi];

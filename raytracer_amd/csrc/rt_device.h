@@ -655,11 +655,10 @@ __device__ inline bool tri_predecessor(const DScene& S, const Ray& ray, const Ke
 // A shape is in the list when it has an odd number of entries before that point, and the
 // list is ordered by each shape's latest entry; so last() is the odd-count shape whose
 // latest entry has the largest key.
-template <bool STATS>
-__device__ inline void containers_n1_n2(const DScene& S, const Ray& ray, const HitRec& h,
-                                        double own_ri, double& n1, double& n2, Counters& cnt,
-                                        TravStack& st) {
-  if (STATS) cnt.pred_queries++;
+
+// The trigger entry: the hit itself for a triangle; for a closed-form shape the first of its
+// own entries within EPSILON of the hit's t.
+__device__ inline Key trigger_key(const DScene& S, const Ray& ray, const HitRec& h) {
   Key K{h.t, h.order, 0};
   if (h.prim >= 0) {
     const DPrim& P = S.prims[h.prim];
@@ -676,6 +675,15 @@ __device__ inline void containers_n1_n2(const DScene& S, const Ray& ray, const H
       }
     }
   }
+  return K;
+}
+
+// Closed-form shapes are enumerated exactly; the triangles' contribution is their
+// predecessor below K (tri_found / tri_best / tri_mesh), found by tri_predecessor.
+template <bool STATS>
+__device__ inline void containers_from(const DScene& S, const Ray& ray, const HitRec& h, const Key& K,
+                                       double own_ri, bool tri_found, const Key& tri_best,
+                                       int tri_mesh, double& n1, double& n2, Counters& cnt) {
   bool have_all = false, have_others = false, own_odd = false;
   Key best_all{0.0, 0u, 0}, best_others{0.0, 0u, 0};
   double ri_all = 1.0, ri_others = 1.0;
@@ -712,21 +720,17 @@ __device__ inline void containers_n1_n2(const DScene& S, const Ray& ray, const H
       have_others = true;
     }
   }
-  if (S.n_meshes > 0) {
-    Key tb{0.0, 0u, 0};
-    int tm = -1;
-    if (tri_predecessor<STATS>(S, ray, K, tb, tm, cnt, st)) {
-      double ri = S.mats[S.meshes[tm].material].refractive_index;
-      if (!have_all || key_less(best_all, tb)) {
-        best_all = tb;
-        ri_all = ri;
-        have_all = true;
-      }
-      if (!have_others || key_less(best_others, tb)) {
-        best_others = tb;
-        ri_others = ri;
-        have_others = true;
-      }
+  if (tri_found) {
+    double ri = S.mats[S.meshes[tri_mesh].material].refractive_index;
+    if (!have_all || key_less(best_all, tri_best)) {
+      best_all = tri_best;
+      ri_all = ri;
+      have_all = true;
+    }
+    if (!have_others || key_less(best_others, tri_best)) {
+      best_others = tri_best;
+      ri_others = ri;
+      have_others = true;
     }
   }
   n1 = have_all ? ri_all : 1.0;
@@ -734,6 +738,18 @@ __device__ inline void containers_n1_n2(const DScene& S, const Ray& ray, const H
     n2 = have_others ? ri_others : 1.0;  // the hit leaves its own shape
   else
     n2 = own_ri;  // the hit enters its own shape, which becomes the last container
+}
+
+template <bool STATS>
+__device__ inline void containers_n1_n2(const DScene& S, const Ray& ray, const HitRec& h,
+                                        double own_ri, double& n1, double& n2, Counters& cnt,
+                                        TravStack& st) {
+  if (STATS) cnt.pred_queries++;
+  Key K = trigger_key(S, ray, h);
+  Key tb{0.0, 0u, 0};
+  int tm = -1;
+  bool tf = (S.n_meshes > 0) && tri_predecessor<STATS>(S, ray, K, tb, tm, cnt, st);
+  containers_from<STATS>(S, ray, h, K, own_ri, tf, tb, tm, n1, n2, cnt);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -778,22 +794,21 @@ struct ShadeOut {
   bool inside;
 };
 
-// prepare_computations (intersect.rs:168-237) + the light loop of shade_hit + the ray
-// set-up of reflected_color / refracted_color / schlick (world.rs:78-165).
-template <bool STATS>
-__device__ inline void shade_hit_local(const DScene& S, const Ray& ray, const HitRec& h,
-                                       ShadeOut& o, Counters& cnt, TravStack& st) {
-  if (STATS) cnt.shade_calls++;
+// The geometric half of prepare_computations (intersect.rs:168-186).
+struct Prep {
+  V3 normal, over, under;
+  int32_t mat_index, parent_group, leaf_prim;  // leaf_prim >= 0: closed-form shape index
+  bool inside;
+};
+__device__ inline Prep prepare_hit(const DScene& S, const Ray& ray, const HitRec& h, V3* point_out = nullptr) {
+  Prep pr;
   V3 point = ray_at(ray, h.t);
   V3 normal;
-  int mat_index;
-  int parent_group;
-  const double* leaf_inv = nullptr;
+  pr.leaf_prim = h.prim;
   if (h.prim >= 0) {
     const DPrim& P = S.prims[h.prim];
-    mat_index = P.material;
-    parent_group = P.parent;
-    leaf_inv = P.inv;
+    pr.mat_index = P.material;
+    pr.parent_group = P.parent;
     V3 lp = point;
     if (P.parent >= 0) lp = point_to_group(S, P.parent, lp);
     lp = xf_point(P.inv, lp);
@@ -803,8 +818,8 @@ __device__ inline void shade_hit_local(const DScene& S, const Ray& ray, const Hi
     const DMesh& M = S.meshes[h.mesh];
     const DTri& T = S.tris[h.tri];
     const DTriN& TN = S.trin[h.tri];
-    mat_index = M.material;
-    parent_group = M.group;
+    pr.mat_index = M.material;
+    pr.parent_group = M.group;
     V3 ln;
     if (T.smooth) {  // smooth_triangle.rs:114-118: (n2*u + n3*v) + n1*((1-u)-v)
       double w = 1.0 - h.u - h.v;
@@ -816,112 +831,146 @@ __device__ inline void shade_hit_local(const DScene& S, const Ray& ray, const Hi
     }
     normal = vnormalize(ln);  // the triangle's own (identity) level of intersect.rs:79-92
   }
-  normal = normal_up_groups(S, parent_group, normal);
-
-  const DMaterial& M = S.mats[mat_index];
+  normal = normal_up_groups(S, pr.parent_group, normal);
   V3 eyev = vneg(ray.d);
-  bool inside = vdot(normal, eyev) < 0.0;
-  if (inside) normal = vmul(normal, -1.0);
-  V3 over = vadd(point, vmul(normal, EPS));
-  V3 under = vsub(point, vmul(normal, EPS));
-  V3 reflectv = vreflect(ray.d, normal);
-  o.point = point;
-  o.over_point = over;
-  o.under_point = under;
-  o.eyev = eyev;
-  o.normalv = normal;
-  o.reflectv = reflectv;
-  o.inside = inside;
+  pr.inside = vdot(normal, eyev) < 0.0;
+  if (pr.inside) normal = vmul(normal, -1.0);
+  pr.normal = normal;
+  pr.over = vadd(point, vmul(normal, EPS));
+  pr.under = vsub(point, vmul(normal, EPS));
+  if (point_out) *point_out = point;
+  return pr;
+}
 
-  // light loop, world.rs:43-52 with lighting() of light.rs:23-85
-  C3 surface = {0.0, 0.0, 0.0};
+// pattern colour at the hit: pattern.inv * object.world_to_object(over_point) (world.rs:50,
+// light.rs:34-35)
+__device__ inline C3 hit_pattern_color(const DScene& S, const DMaterial& M, const Prep& pr) {
   C3 pc = {M.a[0], M.a[1], M.a[2]};
   if (M.pattern_kind != 0) {
-    V3 op = over;  // world.rs:50: world_to_object(over_point)
-    if (parent_group >= 0) op = point_to_group(S, parent_group, op);
-    if (leaf_inv) op = xf_point(leaf_inv, op);
+    V3 op = pr.over;
+    if (pr.parent_group >= 0) op = point_to_group(S, pr.parent_group, op);
+    if (pr.leaf_prim >= 0) op = xf_point(S.prims[pr.leaf_prim].inv, op);
     pc = pattern_color(M, xf_point(M.pinv, op));
   }
-  for (int li = 0; li < S.n_lights; li++) {
-    const DLight& L = S.lights[li];
-    V3 lpos = v3(L.pos[0], L.pos[1], L.pos[2]);
-    // is_shadowed, world.rs:116-134
-    V3 v = vsub(lpos, over);
-    double distance = vmag(v);
-    V3 direction = v3(v.x / distance, v.y / distance, v.z / distance);
-    Ray sr = {over, direction};
-    if (STATS) cnt.rays_shadow++;
-    bool shadow = trace_any<STATS>(S, sr, distance, cnt, st);
-    // lighting
-    C3 eff = {pc.r * L.intensity[0], pc.g * L.intensity[1], pc.b * L.intensity[2]};
-    V3 lightv = direction;  // normalize(light.position - position): the same expression
-    C3 ambient = {eff.r * M.ambient, eff.g * M.ambient, eff.b * M.ambient};
-    double ldn = vdot(lightv, normal);
-    C3 diffuse = {0.0, 0.0, 0.0}, specular = {0.0, 0.0, 0.0};
-    if (!(shadow || ldn < 0.0)) {
-      diffuse = {eff.r * M.diffuse * ldn, eff.g * M.diffuse * ldn, eff.b * M.diffuse * ldn};
-      V3 rv = vreflect(vneg(lightv), normal);
-      double rde = vdot(rv, eyev);
-      if (!(rde <= 0.0)) {
-        double factor = pow(rde, M.shininess);
-        specular = {L.intensity[0] * M.specular * factor, L.intensity[1] * M.specular * factor,
-                    L.intensity[2] * M.specular * factor};
-      }
+  return pc;
+}
+
+// the shadow ray of is_shadowed (world.rs:116-125)
+__device__ __forceinline__ void shadow_ray(const DLight& L, V3 over, Ray& sr, double& distance) {
+  V3 lpos = v3(L.pos[0], L.pos[1], L.pos[2]);
+  V3 v = vsub(lpos, over);
+  distance = vmag(v);
+  sr = {over, v3(v.x / distance, v.y / distance, v.z / distance)};
+}
+
+// lighting() of light.rs:23-85 for one light, added to `surface` (world.rs:44)
+__device__ inline void add_light(const DMaterial& M, const DLight& L, C3 pc, V3 lightv, V3 normal,
+                                 V3 eyev, bool shadow, C3& surface) {
+  C3 eff = {pc.r * L.intensity[0], pc.g * L.intensity[1], pc.b * L.intensity[2]};
+  C3 ambient = {eff.r * M.ambient, eff.g * M.ambient, eff.b * M.ambient};
+  double ldn = vdot(lightv, normal);
+  C3 diffuse = {0.0, 0.0, 0.0}, specular = {0.0, 0.0, 0.0};
+  if (!(shadow || ldn < 0.0)) {
+    diffuse = {eff.r * M.diffuse * ldn, eff.g * M.diffuse * ldn, eff.b * M.diffuse * ldn};
+    V3 rv = vreflect(vneg(lightv), normal);
+    double rde = vdot(rv, eyev);
+    if (!(rde <= 0.0)) {
+      double factor = pow(rde, M.shininess);
+      specular = {L.intensity[0] * M.specular * factor, L.intensity[1] * M.specular * factor,
+                  L.intensity[2] * M.specular * factor};
     }
-    surface.r += ambient.r + diffuse.r + specular.r;
-    surface.g += ambient.g + diffuse.g + specular.g;
-    surface.b += ambient.b + diffuse.b + specular.b;
   }
-  o.surface = surface;
+  surface.r += ambient.r + diffuse.r + specular.r;
+  surface.g += ambient.g + diffuse.g + specular.g;
+  surface.b += ambient.b + diffuse.b + specular.b;
+}
+
+// material flags of shade_hit / reflected_color / refracted_color (world.rs:57-59, 79, 90)
+__device__ __forceinline__ bool needs_n1_n2(const DMaterial& M) {
+  return !feq(M.transparency, 0.0) || ((M.reflective > 0.) && (M.transparency > 0.));
+}
+
+// ray set-up of reflected_color / refracted_color and schlick (world.rs:78-165)
+__device__ inline void finish_optics(const DMaterial& M, const Ray& ray, const Prep& pr, double n1,
+                                     double n2, ShadeOut& o) {
+  V3 eyev = vneg(ray.d);
+  V3 normal = pr.normal;
   o.reflective = M.reflective;
   o.transparency = M.transparency;
   o.do_reflect = !feq(M.reflective, 0.0);  // world.rs:79
-  o.reflect_ray = {over, reflectv};
+  o.reflect_ray = {pr.over, vreflect(ray.d, normal)};
   o.use_schlick = (M.reflective > 0.) && (M.transparency > 0.);  // world.rs:57-59
   o.do_refract = false;
   o.reflectance = 0.0;
-  o.n1 = 1.0;
-  o.n2 = 1.0;
-  bool want_refract = !feq(M.transparency, 0.0);  // world.rs:90
-  if (want_refract || o.use_schlick) {
-    double n1, n2;
-    containers_n1_n2<STATS>(S, ray, h, M.refractive_index, n1, n2, cnt, st);
-    o.n1 = n1;
-    o.n2 = n2;
-    if (want_refract) {  // world.rs:94-112
-      double n_ratio = n1 / n2;
-      double cos_i = vdot(eyev, normal);
-      double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
-      if (!(sin2_t > 1.)) {
-        double cos_t = sqrt(1. - sin2_t);
-        V3 dir = vsub(vmul(normal, n_ratio * cos_i - cos_t), vmul(eyev, n_ratio));
-        o.refract_ray = {under, dir};
-        o.do_refract = true;
-      }
-    }
-    if (o.use_schlick) {  // world.rs:151-165
-      double c = vdot(eyev, normal);
-      bool total = false;
-      if (n1 > n2) {
-        double n = n1 / n2;
-        double sin2_t = n * n * (1. - c * c);
-        if (sin2_t > 1.)
-          total = true;
-        else
-          c = sqrt(1. - sin2_t);
-      }
-      if (total) {
-        o.reflectance = 1.;
-      } else {
-        double q = (n1 - n2) / (n1 + n2);
-        double r0 = q * q;
-        double x = 1. - c;
-        double x2 = x * x;
-        double x5 = x * (x2 * x2);  // powi(5) by repeated squaring
-        o.reflectance = r0 + (1. - r0) * x5;
-      }
+  o.n1 = n1;
+  o.n2 = n2;
+  if (!feq(M.transparency, 0.0)) {  // world.rs:90-112
+    double n_ratio = n1 / n2;
+    double cos_i = vdot(eyev, normal);
+    double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+    if (!(sin2_t > 1.)) {
+      double cos_t = sqrt(1. - sin2_t);
+      V3 dir = vsub(vmul(normal, n_ratio * cos_i - cos_t), vmul(eyev, n_ratio));
+      o.refract_ray = {pr.under, dir};
+      o.do_refract = true;
     }
   }
+  if (o.use_schlick) {  // world.rs:151-165
+    double c = vdot(eyev, normal);
+    bool total = false;
+    if (n1 > n2) {
+      double n = n1 / n2;
+      double sin2_t = n * n * (1. - c * c);
+      if (sin2_t > 1.)
+        total = true;
+      else
+        c = sqrt(1. - sin2_t);
+    }
+    if (total) {
+      o.reflectance = 1.;
+    } else {
+      double q = (n1 - n2) / (n1 + n2);
+      double r0 = q * q;
+      double x = 1. - c;
+      double x2 = x * x;
+      double x5 = x * (x2 * x2);  // powi(5) by repeated squaring
+      o.reflectance = r0 + (1. - r0) * x5;
+    }
+  }
+}
+
+// prepare_computations + the light loop of shade_hit + the child-ray set-up, in one lane.
+template <bool STATS>
+__device__ inline void shade_hit_local(const DScene& S, const Ray& ray, const HitRec& h,
+                                       ShadeOut& o, Counters& cnt, TravStack& st) {
+  if (STATS) cnt.shade_calls++;
+  V3 point;
+  Prep pr = prepare_hit(S, ray, h, &point);
+  const DMaterial& M = S.mats[pr.mat_index];
+  V3 eyev = vneg(ray.d);
+  o.point = point;
+  o.over_point = pr.over;
+  o.under_point = pr.under;
+  o.eyev = eyev;
+  o.normalv = pr.normal;
+  o.reflectv = vreflect(ray.d, pr.normal);
+  o.inside = pr.inside;
+  C3 surface = {0.0, 0.0, 0.0};
+  C3 pc = hit_pattern_color(S, M, pr);
+  for (int li = 0; li < S.n_lights; li++) {
+    const DLight& L = S.lights[li];
+    Ray sr;
+    double distance;
+    shadow_ray(L, pr.over, sr, distance);
+    if (STATS) cnt.rays_shadow++;
+    bool shadow = trace_any<STATS>(S, sr, distance, cnt, st);
+    // lightv = normalize(light.position - position) is the shadow ray's direction
+    add_light(M, L, pc, sr.d, pr.normal, eyev, shadow, surface);
+  }
+  o.surface = surface;
+  double n1 = 1.0, n2 = 1.0;
+  if (needs_n1_n2(M)) containers_n1_n2<STATS>(S, ray, h, M.refractive_index, n1, n2, cnt, st);
+  finish_optics(M, ray, pr, n1, n2, o);
 }
 
 // world.rs:57-64

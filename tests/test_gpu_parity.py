@@ -19,6 +19,16 @@ F64_TOL = 1e-12
 S2 = math.sqrt(2.0)
 
 
+@pytest.fixture(autouse=True, params=["wavefront", "megakernel"])
+def pipeline(request, rt):
+    """Every test runs once per kernel organisation; both must meet the same bar."""
+    old = rt.DEFAULT_PIPELINE
+    rt.DEFAULT_PIPELINE = {"wavefront": rt.PIPELINE_WAVEFRONT,
+                           "megakernel": rt.PIPELINE_MEGAKERNEL}[request.param]
+    yield request.param
+    rt.DEFAULT_PIPELINE = old
+
+
 def u8_report(a, b):
     d = np.abs(a.astype(np.int32) - b.astype(np.int32)).max(axis=-1)
     return float((d == 0).mean()), int(d.max())
