@@ -88,14 +88,32 @@ def main():
         if world_size == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     dist = None
+    # rehearsal of the N-rank code path on a one-GPU box: every rank on cuda:0, gloo with host
+    # staging instead of RCCL (numbers from it mean nothing)
+    rehearsal = os.environ.get("RT_BENCH_REHEARSAL_ONE_GPU") == "1"
     if world_size > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world_size > 1 else 0)
+
+    def all_reduce(t, op=None):
+        kw = {} if op is None else {"op": op}
+        if rehearsal:
+            h = t.cpu()
+            dist.all_reduce(h, **kw)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, **kw)
+        return t
 
     example, hs, vs, ntris, desc = WORKLOADS[args.workload]
     pipeline = {"megakernel": rt.PIPELINE_MEGAKERNEL, "wavefront": rt.PIPELINE_WAVEFRONT}[args.pipeline]
@@ -107,8 +125,21 @@ def main():
     per = max(rt.shard_tiles(hs, vs, s, n) for s in range(n))
     image = torch.zeros((vs, hs, 3), dtype=torch.uint8, device=dev)
     tiles = torch.zeros(per * rt.TILE * rt.TILE * 3, dtype=torch.uint8, device=dev) if n > 1 else None
-    gathered = ([torch.zeros_like(tiles) for _ in range(n)] if (n > 1 and rank == 0) else None)
+    # rank 0 receives every shard straight into its row of one contiguous buffer
     all_tiles = torch.zeros((n, per * rt.TILE * rt.TILE * 3), dtype=torch.uint8, device=dev) if (n > 1 and rank == 0) else None
+    gathered = list(all_tiles.unbind(0)) if all_tiles is not None else None
+
+    def exchange():
+        """The one exchange step: shards -> rank 0 (RCCL gather), de-tile kernel there."""
+        if rehearsal:
+            h = [torch.zeros(tiles.numel(), dtype=torch.uint8) for _ in range(n)] if rank == 0 else None
+            dist.gather(tiles.cpu(), h, dst=0)
+            if rank == 0:
+                all_tiles.copy_(torch.stack(h))
+        else:
+            dist.gather(tiles, gathered, dst=0)
+        if rank == 0:
+            rt.detile_u8(all_tiles.data_ptr(), n, per, hs, vs, image.data_ptr(), stream)
 
     def step(want_stats=False):
         if n == 1:
@@ -116,10 +147,7 @@ def main():
         else:
             w.render_device(d_u8=tiles.data_ptr(), stream=stream, pipeline=pipeline, tile_first=rank,
                             tile_step=n, want_stats=want_stats)
-            dist.gather(tiles, gathered, dst=0)
-            if rank == 0:
-                torch.stack(gathered, out=all_tiles)
-                rt.detile_u8(all_tiles.data_ptr(), n, per, hs, vs, image.data_ptr(), stream)
+            exchange()
 
     # counters of one frame (outside the timed region; deterministic per scene)
     step(want_stats=True)
@@ -128,8 +156,7 @@ def main():
     keys = ["rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "depth0_skipped", "pred_queries",
             "nodes_visited", "tri_tests", "prim_tests", "inst_entries", "shade_calls"]
     if n > 1:
-        t = torch.tensor([st[k] for k in keys], dtype=torch.int64, device=dev)
-        dist.all_reduce(t)
+        t = all_reduce(torch.tensor([st[k] for k in keys], dtype=torch.int64, device=dev))
         st.update({k: int(v) for k, v in zip(keys, t.tolist())})
     rays_per_frame = st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"] + st["rays_refract"]
 
@@ -149,10 +176,7 @@ def main():
         else:
             w.render_device(d_u8=tiles.data_ptr(), stream=stream, pipeline=pipeline, tile_first=rank, tile_step=n)
             ev[i][1].record()
-            dist.gather(tiles, gathered, dst=0)
-            if rank == 0:
-                torch.stack(gathered, out=all_tiles)
-                rt.detile_u8(all_tiles.data_ptr(), n, per, hs, vs, image.data_ptr(), stream)
+            exchange()
     torch.cuda.synchronize()
     if n > 1:
         dist.barrier()
@@ -160,13 +184,14 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # this rank's render kernel(s)
     if n > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = all_reduce(torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
         elapsed, kernel_ms = t.tolist()
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = rays_per_frame / (ms_per_step * 1e3)
+        import zlib
+        frame_crc = zlib.crc32(image.cpu().numpy().tobytes())  # same for every N: the frame is fixed
         abytes, aflops = algorithmic_work(st, info["node_bytes"])
         # per launch: this rank's share of the frame (1/n of the counters for n > 1)
         ach_gbs = abytes / n / (kernel_ms * 1e-3) / 1e9
@@ -181,7 +206,7 @@ def main():
                        "pipeline": args.pipeline, "rays_per_frame": rays_per_frame,
                        "parallelism": f"tiles{rt.TILE}x{rt.TILE} round-robin over {n} GPU(s)" + (", RCCL gather to rank 0" if n > 1 else ""),
                        "triangles": info["n_triangles"], "bvh_nodes": info["n_bvh_nodes"],
-                       "scene_bytes": info["device_bytes"]},
+                       "scene_bytes": info["device_bytes"], "frame_crc32": frame_crc},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": ach_gbs / PEAK_HBM_GBS, "traffic": None,
                          "kernel": "k_render_mega" if args.pipeline == "megakernel" else "wavefront kernels",

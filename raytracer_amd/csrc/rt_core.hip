@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -83,6 +84,85 @@ static bool affine_rows(const double* m16, double* out12, std::string& why) {
     out12[i] = m16[i];
   }
   return true;
+}
+
+// World-space bounds of a closed-form shape: the corners of its object-space bounds
+// (sphere.rs:57-76 and cube.rs:48-82 live in [-1,1]^3; cylinder.rs:53-117 has radius 1
+// between minimum and maximum) pushed through the inverse of (shape inverse x parent
+// inverses), then padded.  Planes, uncapped cylinders and anything numerically doubtful get
+// an infinite box, i.e. are never culled.  So do cones: the single-root branch of
+// cone.rs:93-95 (ray parallel to one half) reports its hit without the minimum/maximum
+// test, anywhere on the infinite double cone.
+static void mat4_mul(const double* a, const double* b, double* o) {
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) {
+      double v = 0.0;
+      for (int k = 0; k < 4; k++) v += a[4 * r + k] * b[4 * k + c];
+      o[4 * r + c] = v;
+    }
+}
+static bool affine_inverse(const double* m, double* o) {
+  // rows 0..2 hold [A | b]; inverse is [A^-1 | -A^-1 b]
+  double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+  double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+  if (!(std::fabs(det) > 1e-300) || !std::isfinite(det)) return false;
+  double inv[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
+                   (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
+                   (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+  for (int r = 0; r < 3; r++) {
+    for (int k = 0; k < 3; k++) o[4 * r + k] = inv[3 * r + k];
+    o[4 * r + 3] = -(inv[3 * r] * m[3] + inv[3 * r + 1] * m[7] + inv[3 * r + 2] * m[11]);
+  }
+  o[12] = o[13] = o[14] = 0.0;
+  o[15] = 1.0;
+  return true;
+}
+static DPrimBox world_box_of(const rt_scene* s, const rt_primitive& P) {
+  const double inf = std::numeric_limits<double>::infinity();
+  DPrimBox B;
+  for (int a = 0; a < 3; a++) {
+    B.lo[a] = -inf;
+    B.hi[a] = inf;
+  }
+  double lo[3] = {-1.0, -1.0, -1.0}, hi[3] = {1.0, 1.0, 1.0};
+  if (P.kind == RT_PLANE || P.kind == RT_CONE) return B;
+  if (P.kind == RT_CYLINDER) {
+    if (!std::isfinite(P.minimum) || !std::isfinite(P.maximum)) return B;
+    lo[1] = std::fmin(P.minimum, P.maximum);
+    hi[1] = std::fmax(P.minimum, P.maximum);
+  }
+  // world -> object: shape inverse applied after the parents' inverses, root first
+  double total[16];
+  std::memcpy(total, P.inv, sizeof total);
+  for (int g = P.parent; g >= 0; g = s->groups[g].parent) {
+    double t[16];
+    mat4_mul(total, s->groups[g].inv, t);
+    std::memcpy(total, t, sizeof total);
+  }
+  double fwd[16], chk[16];
+  if (!affine_inverse(total, fwd)) return B;
+  mat4_mul(total, fwd, chk);
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++)
+      if (!(std::fabs(chk[4 * r + c] - (r == c ? 1.0 : 0.0)) < 1e-9)) return B;
+  double wlo[3] = {inf, inf, inf}, whi[3] = {-inf, -inf, -inf};
+  for (int k = 0; k < 8; k++) {
+    double p[3] = {(k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2]};
+    for (int a = 0; a < 3; a++) {
+      double v = fwd[4 * a] * p[0] + fwd[4 * a + 1] * p[1] + fwd[4 * a + 2] * p[2] + fwd[4 * a + 3];
+      wlo[a] = std::fmin(wlo[a], v);
+      whi[a] = std::fmax(whi[a], v);
+    }
+  }
+  for (int a = 0; a < 3; a++) {
+    if (!std::isfinite(wlo[a]) || !std::isfinite(whi[a])) return B;
+  }
+  for (int a = 0; a < 3; a++) {
+    double pad = 1e-6 * ((whi[a] - wlo[a]) + std::fmax(std::fabs(wlo[a]), std::fabs(whi[a]))) + 1e-9;
+    B.lo[a] = wlo[a] - pad;
+    B.hi[a] = whi[a] + pad;
+  }
+  return B;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -572,6 +652,8 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     P.order = s->prim_order[p];
     P.pad[0] = P.pad[1] = P.pad[2] = 0;
   }
+  std::vector<DPrimBox> prim_boxes(s->prims.size());
+  for (size_t p = 0; p < s->prims.size(); p++) prim_boxes[p] = world_box_of(s, s->prims[p]);
   std::vector<DMaterial> mats(s->mats.size());
   for (size_t m = 0; m < s->mats.size(); m++) {
     DMaterial& M = mats[m];
@@ -667,6 +749,7 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   int rc;
   if ((rc = upload(s, groups, &s->d.groups))) return rc;
   if ((rc = upload(s, prims, &s->d.prims))) return rc;
+  if ((rc = upload(s, prim_boxes, &s->d.prim_boxes))) return rc;
   if ((rc = upload(s, meshes, &s->d.meshes))) return rc;
   if ((rc = upload(s, tris, &s->d.tris))) return rc;
   if ((rc = upload(s, trin, &s->d.trin))) return rc;

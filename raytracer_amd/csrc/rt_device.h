@@ -283,6 +283,30 @@ __device__ __forceinline__ Ray ray_to_prim(const DScene& S, const DPrim& P, cons
   return xf_ray(P.inv, q);
 }
 
+// World-space box test in front of the closed-form shapes: a shape whose padded box the
+// ray misses inside (tlo, thi) cannot contribute an intersection there.  The boxes are
+// padded by 1e-6 of their size, orders of magnitude above the rounding of this f64 slab
+// test; NaN (0 * inf on a ray lying in a face plane) is dropped by fmin/fmax, i.e. passes.
+struct BoxRay {
+  double o[3], inv[3];
+};
+__device__ __forceinline__ BoxRay make_box_ray(const Ray& r) {
+  BoxRay b;
+  b.o[0] = r.o.x; b.o[1] = r.o.y; b.o[2] = r.o.z;
+  b.inv[0] = 1.0 / r.d.x; b.inv[1] = 1.0 / r.d.y; b.inv[2] = 1.0 / r.d.z;
+  return b;
+}
+__device__ __forceinline__ bool box_may_hit(const DPrimBox& B, const BoxRay& r, double tlo, double thi) {
+  double tin = tlo, tout = thi;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    double t0 = (B.lo[a] - r.o[a]) * r.inv[a], t1 = (B.hi[a] - r.o[a]) * r.inv[a];
+    tin = fmax(tin, fmin(t0, t1));
+    tout = fmin(tout, fmax(t0, t1));
+  }
+  return !(tin > tout + 1e-9 * (fabs(tin) + fabs(tout)));
+}
+
 // ---------------------------------------------------------------------------------------
 // BVH traversal.  The hierarchy only culls; what a triangle test returns is the f64
 // arithmetic of moller_trumbore() above, bit for bit.  Culling itself runs in f32 against
@@ -576,7 +600,9 @@ __device__ inline bool trace_closest(const DScene& S, const Ray& ray, HitRec& h,
   q.u = 0.0;
   q.v = 0.0;
   int prim = -1;
+  const BoxRay br = make_box_ray(ray);
   for (int p = 0; p < S.n_prims; p++) {
+    if (!box_may_hit(S.prim_boxes[p], br, 0.0, q.hi)) continue;
     const DPrim& P = S.prims[p];
     Ray lr = ray_to_prim(S, P, ray);
     double ts[4];
@@ -610,7 +636,9 @@ __device__ inline bool trace_closest(const DScene& S, const Ray& ray, HitRec& h,
 template <bool STATS>
 __device__ inline bool trace_any(const DScene& S, const Ray& ray, double distance, Counters& cnt,
                                  TravStack& st) {
+  const BoxRay br = make_box_ray(ray);
   for (int p = 0; p < S.n_prims; p++) {
+    if (!box_may_hit(S.prim_boxes[p], br, 0.0, distance)) continue;
     const DPrim& P = S.prims[p];
     Ray lr = ray_to_prim(S, P, ray);
     double ts[4];
@@ -687,7 +715,10 @@ __device__ inline void containers_from(const DScene& S, const Ray& ray, const Hi
   bool have_all = false, have_others = false, own_odd = false;
   Key best_all{0.0, 0u, 0}, best_others{0.0, 0u, 0};
   double ri_all = 1.0, ri_others = 1.0;
+  const BoxRay br = make_box_ray(ray);
   for (int p = 0; p < S.n_prims; p++) {
+    // only entries below K count, and they have t <= K.t
+    if (!box_may_hit(S.prim_boxes[p], br, -RT_INF, K.t)) continue;
     const DPrim& P = S.prims[p];
     Ray lr = ray_to_prim(S, P, ray);
     double ts[4];

@@ -60,9 +60,15 @@ struct alignas(16) DLight {
   double intensity[3];
   double pos[3];
 };
+// World-space box of one closed-form shape (padded; infinite for planes and uncapped
+// cylinders/cones): rays are tested against it before the shape's own transform and solve.
+struct alignas(16) DPrimBox {
+  double lo[3], hi[3];
+};
 struct DScene {
   const DGroup* groups;
   const DPrim* prims;
+  const DPrimBox* prim_boxes;
   const DMesh* meshes;
   const DTri* tris;
   const DTriN* trin;
