@@ -159,49 +159,41 @@ struct Builder {
   }
 };
 
-// largest float <= x / smallest float >= x
-float round_down(double x) {
-  float f = (float)x;
-  if ((double)f > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
-  return f;
-}
-float round_up(double x) {
-  float f = (float)x;
-  if ((double)f < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
-  return f;
-}
+// The 16-bit grid of one mesh: plane(q) = base + q*cell, q in [0, 65535].
+struct Grid {
+  double base[3], cell[3];
+  // grid step at or below x / at or above x, verified against the f64 plane it stands for
+  uint32_t down(int a, double x) const {
+    if (!(cell[a] > 0.0)) return 0;
+    double q = std::floor((x - base[a]) / cell[a]);
+    if (!(q > 0.0)) return 0;
+    if (q > 65535.0) q = 65535.0;
+    uint32_t k = (uint32_t)q;
+    while (k > 0 && base[a] + k * cell[a] > x) k--;
+    return k;
+  }
+  uint32_t up(int a, double x) const {
+    if (!(cell[a] > 0.0)) return 65535;
+    double q = std::ceil((x - base[a]) / cell[a]);
+    if (!(q > 0.0)) q = 0.0;
+    if (q > 65535.0) return 65535;
+    uint32_t k = (uint32_t)q;
+    while (k < 65535 && base[a] + k * cell[a] < x) k++;
+    return k;
+  }
+};
 
-void set_child(rtd::DNode& N, int which, const Box& b, double pad, int child, int count) {
-  float* lo = which == 0 ? N.lo0 : N.lo1;
-  float* hi = which == 0 ? N.hi0 : N.hi1;
+void set_child(rtd::DNode& N, int which, const Box& b, double pad, const Grid& G, int child) {
   for (int a = 0; a < 3; a++) {
-    lo[a] = round_down(b.lo[a] - pad);
-    hi[a] = round_up(b.hi[a] + pad);
+    uint32_t lo = G.down(a, b.lo[a] - pad), hi = G.up(a, b.hi[a] + pad);
+    N.q[3 * which + a] = lo | (hi << 16);
   }
-  if (which == 0) {
-    N.c0 = child;
-    N.n0 = count;
-  } else {
-    N.c1 = child;
-    N.n1 = count;
-  }
+  (which == 0 ? N.c0 : N.c1) = child;
 }
 
 void set_empty(rtd::DNode& N, int which) {
-  // an inverted, finite box: every slab interval over it is empty
-  float* lo = which == 0 ? N.lo0 : N.lo1;
-  float* hi = which == 0 ? N.hi0 : N.hi1;
-  for (int a = 0; a < 3; a++) {
-    lo[a] = std::numeric_limits<float>::max();
-    hi[a] = -std::numeric_limits<float>::max();
-  }
-  if (which == 0) {
-    N.c0 = -1;
-    N.n0 = 0;
-  } else {
-    N.c1 = -1;
-    N.n1 = 0;
-  }
+  for (int a = 0; a < 3; a++) N.q[3 * which + a] = 0xffffu;  // lo = 65535, hi = 0
+  (which == 0 ? N.c0 : N.c1) = -1;
 }
 
 }  // namespace
@@ -238,6 +230,7 @@ void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, 
   for (int a = 0; a < 3; a++) {
     out.lo[a] = 0.0;
     out.hi[a] = 0.0;
+    out.cell[a] = 0.0;
   }
   rtd::DNode zero{};
   if (n == 0) {
@@ -251,17 +244,23 @@ void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, 
   int root = B.build(0, (int)n, 0);
   out.max_depth = B.max_depth;
   out.order = B.idx;
+  Grid G;
   for (int a = 0; a < 3; a++) {
-    // root bounds as wide as the widest f32 child box can get
-    out.lo[a] = (double)round_down(B.tmp[root].box.lo[a] - pad) - pad;
-    out.hi[a] = (double)round_up(B.tmp[root].box.hi[a] + pad) + pad;
+    // the grid spans the root box padded twice: every child box (padded once) lies strictly
+    // inside it, so clamping to [0, 65535] never cuts a box short
+    double lo = B.tmp[root].box.lo[a] - 2.0 * pad, hi = B.tmp[root].box.hi[a] + 2.0 * pad;
+    G.base[a] = lo;
+    G.cell[a] = (hi - lo) / 65535.0 * (1.0 + 1e-12);
+    out.lo[a] = lo;
+    out.hi[a] = std::max(hi, lo + 65535.0 * G.cell[a]);
+    out.cell[a] = G.cell[a];
   }
 
   // Convert: every inner tmp node becomes one DNode carrying its two children's boxes.
   const TmpNode& R = B.tmp[root];
   if (R.left < 0) {  // the whole mesh is one leaf
     rtd::DNode N = zero;
-    set_child(N, 0, R.box, pad, -2 - ((R.first << 3) | R.count), R.count);
+    set_child(N, 0, R.box, pad, G, -2 - ((R.first << 3) | R.count));
     set_empty(N, 1);
     out.nodes.push_back(N);
     return;
@@ -285,14 +284,8 @@ void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, 
     rtd::DNode& N = out.nodes[i];
     const TmpNode& L = B.tmp[T.left];
     const TmpNode& Rr = B.tmp[T.right];
-    if (L.left >= 0)
-      set_child(N, 0, L.box, pad, map[T.left], 0);
-    else
-      set_child(N, 0, L.box, pad, -2 - ((L.first << 3) | L.count), L.count);
-    if (Rr.left >= 0)
-      set_child(N, 1, Rr.box, pad, map[T.right], 0);
-    else
-      set_child(N, 1, Rr.box, pad, -2 - ((Rr.first << 3) | Rr.count), Rr.count);
+    set_child(N, 0, L.box, pad, G, L.left >= 0 ? map[T.left] : -2 - ((L.first << 3) | L.count));
+    set_child(N, 1, Rr.box, pad, G, Rr.left >= 0 ? map[T.right] : -2 - ((Rr.first << 3) | Rr.count));
   }
 }
 

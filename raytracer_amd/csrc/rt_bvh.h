@@ -15,11 +15,12 @@ struct BuildResult {
   std::vector<rtd::DNode> nodes;  // nodes[0] is the root; child indices are local to this vector
   std::vector<uint32_t> order;    // order[k] = face index of the k-th triangle record
   int max_depth = 0;
-  double lo[3], hi[3];  // padded bounds of the whole mesh
+  double lo[3], hi[3];  // padded bounds of the whole mesh = origin and far end of the node grid
+  double cell[3];       // step of the 16-bit grid the node boxes are stored on
   double scale = 0.0;   // largest |coordinate|
 };
 
-// p1,p2,p3: n x 3 doubles.  max_leaf: triangles per leaf (<= 4).
+// p1,p2,p3: n x 3 doubles.  max_leaf: triangles per leaf (<= 7).
 void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, int max_leaf,
                BuildResult& out);
 

@@ -216,10 +216,7 @@ template <bool STATS>
 __global__ void __launch_bounds__(64)
 k_render_mega(DScene S, DCamera cam, PixelMap pm, int depth, double* out_f64, uint8_t* out_u8,
               unsigned long long* counters) {
-  __shared__ int lds_stack[LDS_STACK * 64];
-  TravStack st;
-  st.lds = lds_stack + threadIdx.x;
-  st.stride = 64;
+  RT_TRAV_STACK(st);
   Counters cnt{};
   int px, py;
   long long oi;
@@ -245,10 +242,7 @@ __global__ void __launch_bounds__(64) k_trace_rays(DScene S, long long n, const 
                              int depth, double* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  __shared__ int lds_stack[LDS_STACK * 64];
-  TravStack st;
-  st.lds = lds_stack + threadIdx.x;
-  st.stride = 64;
+  RT_TRAV_STACK(st);
   Counters cnt{};
   Ray r = {v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
            v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2])};
@@ -334,10 +328,8 @@ __global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
 k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n, WfNode* nodes,
            WfTask* next, unsigned int* next_count, unsigned int next_cap, int spawn,
            unsigned long long* counters) {
-  __shared__ int lds_stack[LDS_STACK * WF_BLOCK];
-  TravStack st;
-  st.lds = lds_stack + threadIdx.x;
-  st.stride = WF_BLOCK;
+  static_assert(WF_BLOCK == 64, "the traversal stack is laid out for 64-lane blocks");
+  RT_TRAV_STACK(st);
   Counters cnt{};
   long long i = (long long)blockIdx.x * WF_BLOCK + threadIdx.x;
   bool active;
@@ -701,6 +693,7 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     for (int a = 0; a < 3; a++) {
       M.lo[a] = br.lo[a];
       M.hi[a] = br.hi[a];
+      M.cell[a] = br.cell[a];
     }
     M.scale = br.scale;
     int32_t node_base = (int32_t)nodes.size();

@@ -310,46 +310,67 @@ __device__ __forceinline__ bool box_may_hit(const DPrimBox& B, const BoxRay& r, 
 // ---------------------------------------------------------------------------------------
 // BVH traversal.  The hierarchy only culls; what a triangle test returns is the f64
 // arithmetic of moller_trumbore() above, bit for bit.  Culling itself runs in f32 against
-// 64-byte nodes (both children's boxes, rounded outward from padded f64 boxes) and is made
-// conservative analytically:
+// 32-byte nodes (both children's boxes as 16-bit steps of a grid over the mesh's padded
+// bounds, rounded outward from padded f64 boxes) and is made conservative analytically:
 //   * the ray is re-based to where it enters the mesh's root box (f64), so every f32
 //     operand is of the mesh's own magnitude S = max |coordinate|;
 //   * a direction component smaller than 1e-10 of the largest is replaced by that bound:
 //     inside the mesh the culling ray then strays from the true one by < 4e-10 S, far below
 //     the 1e-7 S padding of every box, and 1/d stays finite;
-//   * plane distances are one fma each, t = plane * (1/d) + c, with c pre-biased by
-//     E = 4 * 2^-24 * (S + |o|) * |1/d|, which bounds the rounding of 1/d to f32 and of the
-//     fma; c is rounded away from the interval (down for near planes, up for far planes);
+//   * a box plane lo + q*cell is met at t = q * (cell/d) + (lo - o)/d: one fma with
+//     a = f32(cell/d) and c pre-biased by E = 6 * 2^-24 * (S + |o|) * |1/d|, which bounds the
+//     rounding of a (times q <= 65535, i.e. at most the mesh's extent) and of the fma; c is
+//     rounded away from the interval (down for near planes, up for far planes);
 //   * the query interval (0 or the running predecessor below, the closest hit or the
 //     shadow distance or the trigger above) is converted with outward rounding.
 // A child is skipped only if its (enlarged) interval misses the (enlarged) query interval.
 struct NodeR {
-  float lo0[3], hi0[3], lo1[3], hi1[3];
-  int32_t c0, c1, n0, n1;
+  uint32_t q[6];
+  int32_t c0, c1;
 };
 __device__ __forceinline__ NodeR load_node(const DNode* p) {
-  const float4* q = reinterpret_cast<const float4*>(p);
-  float4 a = q[0], b = q[1], c = q[2];
-  int4 m = *reinterpret_cast<const int4*>(q + 3);
+  const uint4* w = reinterpret_cast<const uint4*>(p);
+  uint4 a = w[0], b = w[1];
   NodeR r;
-  r.lo0[0] = a.x; r.lo0[1] = a.y; r.lo0[2] = a.z;
-  r.hi0[0] = a.w; r.hi0[1] = b.x; r.hi0[2] = b.y;
-  r.lo1[0] = b.z; r.lo1[1] = b.w; r.lo1[2] = c.x;
-  r.hi1[0] = c.y; r.hi1[1] = c.z; r.hi1[2] = c.w;
-  r.c0 = m.x; r.c1 = m.y; r.n0 = m.z; r.n1 = m.w;
+  r.q[0] = a.x; r.q[1] = a.y; r.q[2] = a.z; r.q[3] = a.w;
+  r.q[4] = b.x; r.q[5] = b.y;
+  r.c0 = (int32_t)b.z; r.c1 = (int32_t)b.w;
   return r;
 }
-__device__ __forceinline__ DTri load_tri(const DTri* p) {
-  const double2* q = reinterpret_cast<const double2*>(p);
-  double2 a = q[0], b = q[1], c = q[2], d = q[3];
-  uint4 e = *reinterpret_cast<const uint4*>(q + 4);
+// One triangle record as five 16-byte loads.  pin() makes the values live at one point, so
+// the compiler issues all the loads of a batch back to back and waits once, instead of
+// fetching p1 in a second, dependent round trip after the determinant test.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct TriRaw {
+  u32x4 a, b, c, d, e;
+};
+__device__ __forceinline__ TriRaw load_tri_raw(const DTri* p) {
+  const u32x4* q = reinterpret_cast<const u32x4*>(p);
+  TriRaw r;
+  r.a = q[0]; r.b = q[1]; r.c = q[2]; r.d = q[3]; r.e = q[4];
+  return r;
+}
+__device__ __forceinline__ void pin(TriRaw& r) {
+  asm volatile("" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e));
+}
+__device__ __forceinline__ void pin(TriRaw& r, TriRaw& s) {
+  asm volatile(""
+               : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e), "+v"(s.a), "+v"(s.b),
+                 "+v"(s.c), "+v"(s.d), "+v"(s.e));
+}
+__device__ __forceinline__ DTri decode_tri(const TriRaw& r) {
   DTri t;
-  t.p1[0] = a.x; t.p1[1] = a.y; t.p1[2] = b.x;
-  t.e1[0] = b.y; t.e1[1] = c.x; t.e1[2] = c.y;
-  t.e2[0] = d.x; t.e2[1] = d.y;
-  t.e2[2] = __hiloint2double((int)e.y, (int)e.x);
-  t.orig = e.z;
-  t.smooth = e.w;
+  t.p1[0] = __hiloint2double((int)r.a.y, (int)r.a.x);
+  t.p1[1] = __hiloint2double((int)r.a.w, (int)r.a.z);
+  t.p1[2] = __hiloint2double((int)r.b.y, (int)r.b.x);
+  t.e1[0] = __hiloint2double((int)r.b.w, (int)r.b.z);
+  t.e1[1] = __hiloint2double((int)r.c.y, (int)r.c.x);
+  t.e1[2] = __hiloint2double((int)r.c.w, (int)r.c.z);
+  t.e2[0] = __hiloint2double((int)r.d.y, (int)r.d.x);
+  t.e2[1] = __hiloint2double((int)r.d.w, (int)r.d.z);
+  t.e2[2] = __hiloint2double((int)r.e.y, (int)r.e.x);
+  t.orig = r.e.z;
+  t.smooth = r.e.w;
   return t;
 }
 
@@ -362,15 +383,15 @@ __device__ __forceinline__ float f32_down(double x) {  // largest float <= x
 __device__ __forceinline__ float f32_up(double x) { return -f32_down(-x); }
 
 struct CullRay {
-  float id[3];  // 1/d of the culling ray
+  float a[3];   // cell / d of the culling ray
   float cn[3];  // near-plane offsets, biased down
   float cf[3];  // far-plane offsets, biased up
-  bool neg[3];  // direction negative: the near plane of that axis is `hi`
+  int sh[3];    // bit offset of the near plane's step in a node word: 16 if d < 0 else 0
   double t_base;
   bool miss;  // the ray does not touch the mesh's root box at all
 };
 
-// lo/hi: the mesh's padded root box; want_negative: the query reaches behind the origin.
+// want_negative: the query reaches behind the origin.
 __device__ inline CullRay make_cull_ray(const DMesh& M, const Ray& lr, bool want_negative) {
   CullRay c;
   const double o[3] = {lr.o.x, lr.o.y, lr.o.z};
@@ -396,32 +417,34 @@ __device__ inline CullRay make_cull_ray(const DMesh& M, const Ray& lr, bool want
     double dmin = dmax * 1e-10;
     if (!(fabs(da) >= dmin)) da = (da < 0.0) ? -dmin : dmin;
     double inv = 1.0 / da;
-    double oid = oa * inv;
-    double E = (4.0 * 5.9604644775390625e-08) * (M.scale + fabs(oa)) * fabs(inv);
-    c.neg[a] = da < 0.0;
+    double oid = (M.lo[a] - oa) * inv;
+    double E = (6.0 * 5.9604644775390625e-08) * (M.scale + fabs(oa)) * fabs(inv);
+    c.sh[a] = (da < 0.0) ? 16 : 0;
     if (degenerate || !(fabs(oid) < 1e30) || !(fabs(inv) < 1e30)) {
-      c.id[a] = 0.0f;  // no culling on this axis
+      c.a[a] = 0.0f;  // no culling on this axis
       c.cn[a] = -__builtin_huge_valf();
       c.cf[a] = __builtin_huge_valf();
     } else {
-      c.id[a] = (float)inv;
-      c.cn[a] = f32_down(-oid - E);
-      c.cf[a] = f32_up(-oid + E);
+      c.a[a] = (float)(M.cell[a] * inv);
+      c.cn[a] = f32_down(oid - E);
+      c.cf[a] = f32_up(oid + E);
     }
   }
   return c;
 }
 
-// Enlarged parametric interval (in t - t_base) of one child box.
-__device__ __forceinline__ void slab32(const float lo[3], const float hi[3], const CullRay& c,
-                                       float& tn, float& tf) {
-  float nx = c.neg[0] ? hi[0] : lo[0], fx = c.neg[0] ? lo[0] : hi[0];
-  float ny = c.neg[1] ? hi[1] : lo[1], fy = c.neg[1] ? lo[1] : hi[1];
-  float nz = c.neg[2] ? hi[2] : lo[2], fz = c.neg[2] ? lo[2] : hi[2];
-  tn = fmaxf(fmaxf(__fmaf_rn(nx, c.id[0], c.cn[0]), __fmaf_rn(ny, c.id[1], c.cn[1])),
-             __fmaf_rn(nz, c.id[2], c.cn[2]));
-  tf = fminf(fminf(__fmaf_rn(fx, c.id[0], c.cf[0]), __fmaf_rn(fy, c.id[1], c.cf[1])),
-             __fmaf_rn(fz, c.id[2], c.cf[2]));
+// Enlarged parametric interval (in t - t_base) of one child box (three node words).
+__device__ __forceinline__ void slab32(const uint32_t* q, const CullRay& c, float& tn, float& tf) {
+  float n[3], f[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    float qn = (float)__builtin_amdgcn_ubfe(q[a], (uint32_t)c.sh[a], 16u);
+    float qf = (float)__builtin_amdgcn_ubfe(q[a], (uint32_t)(16 - c.sh[a]), 16u);
+    n[a] = __fmaf_rn(qn, c.a[a], c.cn[a]);
+    f[a] = __fmaf_rn(qf, c.a[a], c.cf[a]);
+  }
+  tn = fmaxf(fmaxf(n[0], n[1]), n[2]);
+  tf = fminf(fminf(f[0], f[1]), f[2]);
 }
 
 struct HitRec {
@@ -432,25 +455,33 @@ struct HitRec {
   int32_t tri;  // global record index in the triangle table
 };
 
-// Traversal stack of one lane: the first LDS_STACK entries live in LDS (entry i of lane l at
-// lds[i*stride + l]: lanes of a wave touch distinct banks whatever their depths), deeper
-// entries spill to a private array that well-built trees never reach.
+// Traversal stack of one lane of a 64-lane block: the first LDS_STACK entries live in LDS
+// (entry i of lane l at word i*64 + l: the lanes of a wave touch distinct banks whatever
+// their depths), deeper entries spill to a private array that well-built trees never reach.
+// The LDS pointer carries its address space so pushes and pops are plain ds_write/ds_read.
 constexpr int STACK_MAX = 64;
 constexpr int LDS_STACK = 24;
+typedef __attribute__((address_space(3))) int lds_int;
 struct TravStack {
-  int* lds;
-  int stride;
-  int spill[STACK_MAX - LDS_STACK];
+  lds_int* lds;  // this lane's column
+  int* spill;    // STACK_MAX - LDS_STACK private words
   __device__ __forceinline__ void put(int i, int v) {
     if (i < LDS_STACK)
-      lds[i * stride] = v;
+      lds[i * 64] = v;
     else
       spill[i - LDS_STACK] = v;
   }
   __device__ __forceinline__ int get(int i) const {
-    return i < LDS_STACK ? lds[i * stride] : spill[i - LDS_STACK];
+    return i < LDS_STACK ? lds[i * 64] : spill[i - LDS_STACK];
   }
 };
+// In a kernel of 64-thread blocks: RT_TRAV_STACK(st) declares the storage and the handle.
+#define RT_TRAV_STACK(name)                                                     \
+  __shared__ int name##_lds[rtd::LDS_STACK * 64];                               \
+  int name##_spill[rtd::STACK_MAX - rtd::LDS_STACK];                            \
+  rtd::TravStack name;                                                          \
+  name.lds = (rtd::lds_int*)(name##_lds) + threadIdx.x;                         \
+  name.spill = name##_spill
 
 // Sort key of one entry of the reference's intersection list: ascending t, ties by leaf
 // order, then by emission order inside one shape (stable sorts, group.rs:69, world.rs:29).
@@ -482,35 +513,50 @@ struct Query {
 };
 
 template <int MODE, bool STATS>
-__device__ __forceinline__ bool test_leaf(const DMesh& M, int m, const DTri* tris, int first, int count,
-                                          const Ray& lr, Query& q, Counters& cnt) {
-  for (int k = 0; k < count; k++) {
-    const DTri T = load_tri(tris + first + k);
-    double t, u, v;
-    if (STATS) cnt.tri_tests++;
-    if (!moller_trumbore(T, lr, t, u, v)) continue;
-    uint32_t ord = M.order_base + T.orig;
-    if (MODE == Q_CLOSEST) {
-      if (t > 0.0 && (t < q.hi || (t == q.hi && ord < q.hi_order))) {
-        q.hi = t;
-        q.hi_order = ord;
-        q.mesh = m;
-        q.tri = M.tri_base + first + k;
-        q.u = u;
-        q.v = v;
-        q.found = true;
-      }
-    } else if (MODE == Q_ANY) {
-      if (t > 0.0 && t < q.hi) return true;
-    } else {
-      Key c{t, ord, 0};
-      Key K{q.hi, q.hi_order, 0};
-      if (key_less(c, K) && (!q.found || key_less(q.best, c))) {
-        q.best = c;
-        q.mesh = m;
-        q.found = true;
-      }
+__device__ __forceinline__ bool test_tri(const DTri& T, uint32_t order_base, int m, int rec,
+                                         const Ray& lr, Query& q, Counters& cnt) {
+  double t, u, v;
+  if (STATS) cnt.tri_tests++;
+  if (!moller_trumbore(T, lr, t, u, v)) return false;
+  uint32_t ord = order_base + T.orig;
+  if (MODE == Q_CLOSEST) {
+    if (t > 0.0 && (t < q.hi || (t == q.hi && ord < q.hi_order))) {
+      q.hi = t;
+      q.hi_order = ord;
+      q.mesh = m;
+      q.tri = rec;
+      q.u = u;
+      q.v = v;
+      q.found = true;
     }
+  } else if (MODE == Q_ANY) {
+    if (t > 0.0 && t < q.hi) return true;
+  } else {
+    Key c{t, ord, 0};
+    Key K{q.hi, q.hi_order, 0};
+    if (key_less(c, K) && (!q.found || key_less(q.best, c))) {
+      q.best = c;
+      q.mesh = m;
+      q.found = true;
+    }
+  }
+  return false;
+}
+
+// The triangles of one leaf, two at a time: both records are in flight together.  Which
+// triangle wins does not depend on the test order (the comparisons carry the leaf order).
+template <int MODE, bool STATS>
+__device__ __forceinline__ bool test_leaf(uint32_t order_base, int tri_base, int m, const DTri* tris,
+                                          int first, int count, const Ray& lr, Query& q,
+                                          Counters& cnt) {
+  for (int k = 0; k < count; k += 2) {
+    const bool two = k + 1 < count;
+    TriRaw r0 = load_tri_raw(tris + first + k);
+    TriRaw r1 = load_tri_raw(tris + first + (two ? k + 1 : k));
+    pin(r0, r1);
+    if (test_tri<MODE, STATS>(decode_tri(r0), order_base, m, tri_base + first + k, lr, q, cnt)) return true;
+    if (two && test_tri<MODE, STATS>(decode_tri(r1), order_base, m, tri_base + first + k + 1, lr, q, cnt))
+      return true;
   }
   return false;
 }
@@ -525,7 +571,9 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
     if (STATS) cnt.inst_entries++;
     CullRay c = make_cull_ray(M, lr, MODE == Q_PRED);
     if (c.miss) continue;
-    const DTri* tris = S.tris + M.tri_base;
+    const int tri_base = M.tri_base;
+    const uint32_t order_base = M.order_base;
+    const DTri* tris = S.tris + tri_base;
     // query interval in t - t_base, rounded outward
     float qlo, qhi;
     if (MODE == Q_PRED) {
@@ -551,10 +599,10 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
           if (visited > cnt.max_nodes) cnt.max_nodes = visited;
         }
         float tn0, tf0, tn1, tf1;
-        slab32(N.lo0, N.hi0, c, tn0, tf0);
-        slab32(N.lo1, N.hi1, c, tn1, tf1);
-        bool h0 = fmaxf(tn0, qlo) <= fminf(tf0, qhi);
-        bool h1 = fmaxf(tn1, qlo) <= fminf(tf1, qhi);
+        slab32(N.q, c, tn0, tf0);
+        slab32(N.q + 3, c, tn1, tf1);
+        bool h0 = fmaxf(tn0, qlo) <= fminf(tf0, qhi) && N.c0 != -1;
+        bool h1 = fmaxf(tn1, qlo) <= fminf(tf1, qhi) && N.c1 != -1;
         if (h0 && h1) {
           // Q_CLOSEST / Q_ANY: nearer child first; Q_PRED: the child reaching further up first
           bool second_first = (MODE == Q_PRED) ? (tf1 > tf0) : (tn1 < tn0);
@@ -572,7 +620,7 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
       }
       if (cur != -1) {
         int code = -2 - cur;
-        if (test_leaf<MODE, STATS>(M, m, tris, code >> 3, code & 7, lr, q, cnt)) return true;
+        if (test_leaf<MODE, STATS>(order_base, tri_base, m, tris, code >> 3, code & 7, lr, q, cnt)) return true;
         // a leaf may have tightened the interval
         if (MODE == Q_CLOSEST) {
           if (q.hi < 1e300) qhi = f32_up(q.hi - c.t_base);

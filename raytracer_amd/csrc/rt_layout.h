@@ -23,6 +23,7 @@ struct alignas(16) DPrim {
 };
 struct alignas(16) DMesh {
   double lo[3], hi[3];  // padded bounds of the whole mesh (object space)
+  double cell[3];       // size of one step of the node boxes' 16-bit grid: plane = lo + q*cell
   double scale;         // largest |coordinate| of the mesh
   int32_t group, material;
   uint32_t order_base;  // leaf order of triangle 0
@@ -41,13 +42,14 @@ struct alignas(16) DTri {
 struct alignas(8) DTriN {
   double n[9];
 };
-// Binary BVH node holding the boxes of BOTH children in f32 (rounded outward from the padded
-// f64 boxes), so one 64-byte fetch decides both.  Child c >= 0: inner node index; c == -1:
-// no child (its box is inverted); c <= -2: leaf, code = -2 - c = (first << 3) | count with
-// `first` relative to the mesh's tri_base and count <= 4 (n0/n1 repeat the counts).
-struct alignas(64) DNode {
-  float lo0[3], hi0[3], lo1[3], hi1[3];
-  int32_t c0, c1, n0, n1;
+// Binary BVH node holding the boxes of BOTH children, so one 32-byte fetch decides both.
+// Box planes are 16-bit steps of a grid laid over the mesh's padded bounds (DMesh lo/cell),
+// rounded outward: q[a] = lo_q | hi_q << 16 for child 0 on axis a, q[3+a] for child 1.
+// Child c >= 0: inner node index; c == -1: no child; c <= -2: leaf, code = -2 - c =
+// (first << 3) | count with `first` relative to the mesh's tri_base and count <= 7.
+struct alignas(32) DNode {
+  uint32_t q[6];
+  int32_t c0, c1;
 };
 struct alignas(16) DMaterial {
   double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;

@@ -112,6 +112,46 @@ def test_synthetic_scene_small(rt, O):
     assert np.array_equal(bu, u8[ys, xs])
 
 
+def test_synthetic_full_size(rt, O, pipeline):
+    """The 1M-triangle stress config at its full 3840x2160: every pixel against the oracle's
+    culling mode, a 1024-pixel sample against its brute-force mode (every ray against every
+    triangle, like the reference).  The oracle work is shared by running once."""
+    if pipeline != "wavefront":
+        pytest.skip("both pipelines are rendered in the wavefront instance of this test")
+    n = 1000000
+    w = rt.World.example("synthetic", 3840, 2160, synthetic_tris=n).commit()
+    a, _, sta = w.render(pipeline=rt.PIPELINE_WAVEFRONT, want_stats=True)
+    b, _, stb = w.render(pipeline=rt.PIPELINE_MEGAKERNEL, want_stats=True)
+    assert np.array_equal(a, b)
+    sc = O.Scene.example("synthetic", 3840, 2160, synthetic_tris=n).use_bvh()
+    _, ou8, cnt = sc.render()
+    exact, worst = u8_report(a, ou8)
+    assert exact == 1.0, (exact, worst)
+    for st in (sta, stb):
+        assert (st.rays_primary, st.rays_shadow, st.rays_reflect, st.rays_refract) == (
+            cnt["primary"], cnt["shadow"], cnt["reflect"], cnt["refract"])
+    brute = O.Scene.example("synthetic", 3840, 2160, synthetic_tris=n)
+    rng = np.random.default_rng(5)
+    xs, ys = rng.integers(0, 3840, 1024), rng.integers(0, 2160, 1024)
+    _, bu, _ = brute.render_pixels(xs, ys)
+    assert np.array_equal(bu, a[ys, xs])
+
+
+def test_pawn_8k_sample(rt, O, pipeline):
+    """The 7680x4320 pawn frame (33 M pixels): 150 000 random pixels and 8 full rows against
+    the oracle, and the frame's ray count against 16x the per-pixel average of the sample."""
+    w = rt.World.example("pawn", 7680, 4320).commit()
+    u8, _, st = w.render(want_stats=True)
+    sc = O.Scene.example("pawn", 7680, 4320).use_bvh()
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.integers(0, 7680, 150000), np.tile(np.arange(7680), 8)]).astype(np.int32)
+    ys = np.concatenate([rng.integers(0, 4320, 150000), np.repeat(np.arange(8) * 540 + 270, 7680)]).astype(np.int32)
+    _, ou8, cnt = sc.render_pixels(xs, ys)
+    exact, worst = u8_report(u8[ys, xs], ou8)
+    assert exact == 1.0, (exact, worst)
+    assert st.rays_primary == 7680 * 4320
+
+
 # ---- random and adversarial scenes -------------------------------------------------------------
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_scenes(rt, O, seed):
