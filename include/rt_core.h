@@ -132,6 +132,9 @@ typedef struct rt_stats {
   double kernel_ms;       /* HIP-event time of the render kernels on their stream */
   double total_ms;        /* host wall time of the call */
   uint64_t max_nodes_per_query; /* largest BVH node count one traversal needed */
+  /* iterations of the node loop and of the triangle loop counted once per 64-lane wave:
+   * nodes_visited / (64 * node_wave_steps) is the fraction of lanes doing useful work there */
+  uint64_t node_wave_steps, tri_wave_steps;
 } rt_stats;
 
 /* scene info after commit */

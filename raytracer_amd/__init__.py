@@ -72,7 +72,8 @@ class Stats(C.Structure):
         "rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "depth0_skipped",
         "pred_queries", "nodes_visited", "tri_tests", "prim_tests", "inst_entries", "shade_calls",
         "launches")] + [("kernel_ms", C.c_double), ("total_ms", C.c_double),
-                        ("max_nodes_per_query", C.c_uint64)]
+                        ("max_nodes_per_query", C.c_uint64), ("node_wave_steps", C.c_uint64),
+                        ("tri_wave_steps", C.c_uint64)]
 
     def rays(self):
         return self.rays_primary + self.rays_shadow + self.rays_reflect + self.rays_refract
@@ -83,6 +84,8 @@ class Stats(C.Structure):
         d["total_ms"] = float(self.total_ms)
         d["rays"] = int(self.rays())
         d["max_nodes_per_query"] = int(self.max_nodes_per_query)
+        d["node_wave_steps"] = int(self.node_wave_steps)
+        d["tri_wave_steps"] = int(self.tri_wave_steps)
         return d
 
 

@@ -321,7 +321,7 @@ struct alignas(16) WfNode {
 constexpr int WF_BLOCK = 64;
 
 #ifndef WF_WAVES
-#define WF_WAVES 2
+#define WF_WAVES 4
 #endif
 template <bool STATS, bool PRIMARY>
 __global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
@@ -947,6 +947,8 @@ int rt_render_stats(rt_scene* s, rt_stats* st) {
   st->prim_tests = c[8];
   st->inst_entries = c[9];
   st->shade_calls = c[10];
+  st->node_wave_steps = c[11];
+  st->tri_wave_steps = c[12];
   st->launches = s->launches;
   return RT_OK;
 }

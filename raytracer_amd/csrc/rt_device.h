@@ -447,6 +447,12 @@ __device__ __forceinline__ void slab32(const uint32_t* q, const CullRay& c, floa
   tf = fminf(fminf(f[0], f[1]), f[2]);
 }
 
+// true on the first active lane of the wave (statistics: counts an event once per wave)
+__device__ __forceinline__ bool wave_leader() {
+  unsigned long long m = __ballot(1);
+  return (int)__lane_id() == __ffsll((long long)m) - 1;
+}
+
 struct HitRec {
   double t, u, v;
   uint32_t order;
@@ -516,7 +522,10 @@ template <int MODE, bool STATS>
 __device__ __forceinline__ bool test_tri(const DTri& T, uint32_t order_base, int m, int rec,
                                          const Ray& lr, Query& q, Counters& cnt) {
   double t, u, v;
-  if (STATS) cnt.tri_tests++;
+  if (STATS) {
+    if (wave_leader()) cnt.tri_wave_steps++;
+    cnt.tri_tests++;
+  }
   if (!moller_trumbore(T, lr, t, u, v)) return false;
   uint32_t ord = order_base + T.orig;
   if (MODE == Q_CLOSEST) {
@@ -594,6 +603,7 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
       while (cur >= 0) {
         const NodeR N = load_node(S.nodes + cur);
         if (STATS) {
+          if (wave_leader()) cnt.node_wave_steps++;
           cnt.nodes_visited++;
           visited++;
           if (visited > cnt.max_nodes) cnt.max_nodes = visited;

@@ -87,9 +87,10 @@ struct DCamera {
 
 struct Counters {
   unsigned long long rays_primary, rays_shadow, rays_reflect, rays_refract, depth0_skipped,
-      pred_queries, nodes_visited, tri_tests, prim_tests, inst_entries, shade_calls;
+      pred_queries, nodes_visited, tri_tests, prim_tests, inst_entries, shade_calls,
+      node_wave_steps, tri_wave_steps;  // iterations of the node / triangle loop, per wave
   unsigned long long max_nodes;  // not a sum: the longest single traversal (nodes)
 };
-constexpr int N_COUNTERS = 11;  // summed counters; max_nodes is stored after them
+constexpr int N_COUNTERS = 13;  // summed counters; max_nodes is stored after them
 
 }  // namespace rtd
