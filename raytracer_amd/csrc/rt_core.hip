@@ -325,9 +325,9 @@ constexpr int WF_BLOCK = 64;
 #endif
 template <bool STATS, bool PRIMARY>
 __global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
-k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n, WfNode* nodes,
-           WfTask* next, unsigned int* next_count, unsigned int next_cap, int spawn,
-           unsigned long long* counters) {
+k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n, long long n_front,
+           unsigned int cap, WfNode* nodes, WfTask* next, unsigned int* next_count,
+           unsigned int next_cap, int spawn, unsigned long long* counters) {
   static_assert(WF_BLOCK == 64, "the traversal stack is laid out for 64-lane blocks");
   RT_TRAV_STACK(st);
   Counters cnt{};
@@ -350,7 +350,8 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
   } else {
     active = i < n;
     if (active) {
-      const WfTask& T = tasks[i];
+      // reflected rays fill the queue from the front, refracted rays from the back
+      const WfTask& T = tasks[i < n_front ? i : (long long)cap - 1 - (i - n_front)];
       ray = {v3(T.o[0], T.o[1], T.o[2]), v3(T.d[0], T.d[1], T.d[2])};
       nd.parent = T.parent;
       nd.coef = T.coef;
@@ -398,9 +399,9 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
       }
       if (so.do_refract) {
         if (spawn) {
-          unsigned int idx = atomicAdd(next_count, 1u);
+          unsigned int idx = atomicAdd(next_count + 1, 1u);
           if (idx < next_cap) {
-            WfTask& T = next[idx];
+            WfTask& T = next[next_cap - 1 - idx];
             T.o[0] = so.refract_ray.o.x;
             T.o[1] = so.refract_ray.o.y;
             T.o[2] = so.refract_ray.o.z;
@@ -819,11 +820,13 @@ static int wf_ensure(void** p, size_t* cap, size_t need, size_t elem) {
 static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, int64_t ntiles,
                             int depth, double* d_f64, uint8_t* d_u8, hipStream_t st, bool stats) {
   if (!s->wf_counts) {
-    HIP_TRY(hipMalloc(&s->wf_counts, (MAX_DEPTH + 2) * sizeof(unsigned int)));
-    HIP_TRY(hipHostMalloc(&s->wf_counts_host, (MAX_DEPTH + 2) * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(&s->wf_counts, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int)));
+    HIP_TRY(hipHostMalloc(&s->wf_counts_host, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int)));
   }
-  HIP_TRY(hipMemsetAsync(s->wf_counts, 0, (MAX_DEPTH + 2) * sizeof(unsigned int), st));
+  HIP_TRY(hipMemsetAsync(s->wf_counts, 0, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int), st));
   long long n = ntiles * (RT_TILE * RT_TILE);
+  long long n_front = n;     // level 0 has no queue
+  unsigned int cap_in = 0;
   long long level_n[MAX_DEPTH + 1];
   int levels = 0;
   int rc;
@@ -840,10 +843,10 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     WfNode* nodes = static_cast<WfNode*>(s->wf_nodes[l]);
     WfTask* tnext = spawn ? static_cast<WfTask*>(s->wf_tasks[l + 1]) : nullptr;
     unsigned int cap = spawn ? (unsigned int)std::min<size_t>(s->wf_task_cap[l + 1], 0xffffffffu) : 0u;
-    unsigned int* cnt_next = s->wf_counts + l + 1;
-#define WF_LAUNCH(ST, PR)                                                                       \
-  hipLaunchKernelGGL((k_wf_level<ST, PR>), grid, block, 0, st, s->d, dc, pm, tin, n, nodes, tnext, \
-                     cnt_next, cap, spawn ? 1 : 0, s->d_counters)
+    unsigned int* cnt_next = s->wf_counts + 2 * (l + 1);
+#define WF_LAUNCH(ST, PR)                                                                        \
+  hipLaunchKernelGGL((k_wf_level<ST, PR>), grid, block, 0, st, s->d, dc, pm, tin, n, n_front, cap_in, \
+                     nodes, tnext, cnt_next, cap, spawn ? 1 : 0, s->d_counters)
     if (l == 0) {
       if (stats) WF_LAUNCH(true, true); else WF_LAUNCH(false, true);
     } else {
@@ -855,10 +858,12 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     level_n[l] = n;
     levels = l + 1;
     if (!spawn) break;
-    HIP_TRY(hipMemcpyAsync(s->wf_counts_host + l + 1, cnt_next, sizeof(unsigned int),
+    HIP_TRY(hipMemcpyAsync(s->wf_counts_host + 2 * (l + 1), cnt_next, 2 * sizeof(unsigned int),
                            hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    n = s->wf_counts_host[l + 1];
+    n_front = s->wf_counts_host[2 * (l + 1)];
+    n = n_front + s->wf_counts_host[2 * (l + 1) + 1];
+    cap_in = cap;
     if (n == 0) break;
   }
   for (int l = levels - 1; l >= 0; l--) {
