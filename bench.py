@@ -45,26 +45,45 @@ def algorithmic_work(st, node_bytes):
     return b, f
 
 
-def cpu_baseline(example, hs, vs, ntris, pixels):
+def cpu_baseline(example, hs, vs, ntris, pixels, target_s=12.0):
     """The CPU oracle (brute force, as the reference: every ray against every triangle) on a
-    strided sample of the frame's pixels, all host threads."""
+    strided sample of the frame's pixels, all host threads.  A short calibration run sizes
+    the sample so that the timed run takes about `target_s` seconds."""
     from oracle import oracle as O
     threads = O.default_threads()
     sc = O.Scene.example(example, hs, vs, synthetic_tris=ntris)
     if ntris:
         sc.use_bvh()  # brute force over 1M triangles is not feasible; say so in `sample`
     n = hs * vs
-    idx = (np.arange(pixels, dtype=np.int64) * (n // pixels) + (n // pixels) // 2) % n
-    xs, ys = (idx % hs).astype(np.int32), (idx // hs).astype(np.int32)
-    t0 = time.time()
-    _, _, cnt = sc.render_pixels(xs, ys, threads=threads)
-    dt = time.time() - t0
-    rays = cnt["primary"] + cnt["shadow"] + cnt["reflect"] + cnt["refract"]
+
+    def run(count):
+        idx = (np.arange(count, dtype=np.int64) * n // count + (n // count) // 2) % n
+        xs, ys = (idx % hs).astype(np.int32), (idx // hs).astype(np.int32)
+        t0 = time.time()
+        _, _, cnt = sc.render_pixels(xs, ys, threads=threads)
+        dt = time.time() - t0
+        return cnt["primary"] + cnt["shadow"] + cnt["reflect"] + cnt["refract"], dt
+
+    rays, dt = run(pixels)
+    if dt < target_s / 2:
+        pixels = int(min(n, pixels * min(64.0, target_s / max(dt, 1e-3))))
+        rays, dt = run(pixels)
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"{pixels} pixels on a uniform stride over the {hs}x{vs} frame, "
                       f"{rays} rays, {dt:.2f} s wall, "
                       + ("oracle culling mode (brute force infeasible)" if ntris else
                          "brute force over all triangles like the reference")}
+
+
+def measured_traffic(workload, pipeline):
+    """HBM bytes per frame of the render kernels from the committed rocprofv3 PMC passes of
+    this same command (FETCH_SIZE doubled as gfx950 requires, plus WRITE_SIZE), or None."""
+    path = os.path.join(REPO, "profiles", f"r01_{pipeline}_{workload}_pmc.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["render_kernels_per_frame"]["hbm_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -208,11 +227,14 @@ def main():
                        "triangles": info["n_triangles"], "bvh_nodes": info["n_bvh_nodes"],
                        "scene_bytes": info["device_bytes"], "frame_crc32": frame_crc},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / PEAK_HBM_GBS, "traffic": None,
-                         "kernel": "k_render_mega" if args.pipeline == "megakernel" else "wavefront kernels",
+                         "frac": ach_gbs / PEAK_HBM_GBS,
+                         "traffic": measured_traffic(args.workload, args.pipeline) if n == 1 else None,
+                         "kernel": "k_render_mega" if args.pipeline == "megakernel" else
+                                   "k_wf_level (one launch per recursion level; the frame's launches taken together)",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes / n,
-                         "note": "algorithmic bytes = node_bytes*nodes_visited + 72*tri_tests + 72*shade_calls; "
-                                 "the working set is L2/MALL resident, so HBM is not what binds this kernel"},
+                         "note": "algorithmic bytes = node_bytes*nodes_visited + 72*tri_tests + 72*shade_calls per frame; "
+                                 "traffic = HBM bytes per frame from profiles/ (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE); "
+                                 "the scene is L2/MALL resident, so HBM is not what binds this kernel"},
             "roofline_valu_f64": {"bound": "valu_f64", "achieved": ach_tf, "peak": PEAK_F64_TFLOPS,
                                   "unit": "TFLOP/s", "frac": ach_tf / PEAK_F64_TFLOPS,
                                   "algorithmic_flops_per_launch": aflops / n},

@@ -1,0 +1,42 @@
+"""Condense gpurun_out/prof_<tag> (scripts/profile_gpu.sh) into the files kept under profiles/:
+  <out>_kernel_stats.csv  rocprofv3 --kernel-trace --stats summary, verbatim
+  <out>_pmc.json          per-kernel means of every PMC pass + per-frame HBM traffic
+  <out>_bench.json        the bench line printed under the stats pass
+usage: python scripts/summarise_profile.py <tag> <out-prefix> <frames-per-run>"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+
+tag, out, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
+root = f"gpurun_out/prof_{tag}"
+shutil.copy(glob.glob(f"{root}/stats/*/*kernel_stats.csv")[0], f"{out}_kernel_stats.csv")
+shutil.copy(f"{root}/stats_bench.json", f"{out}_bench.json")
+per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"{root}/pmc_*/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        per_kernel[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary = {}
+fetch_kb = write_kb = 0.0
+for k, cs in sorted(per_kernel.items()):
+    summary[k] = {c: {"launches": len(v), "mean_per_launch": sum(v) / len(v), "sum": sum(v)} for c, v in sorted(cs.items())}
+    if k.startswith(("void k_wf", "void k_render", "k_wf", "k_render")):
+        fetch_kb += sum(cs.get("FETCH_SIZE", []))
+        write_kb += sum(cs.get("WRITE_SIZE", []))
+doc = {
+    "command": "rocprofv3 --pmc <one pass per group> -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline",
+    "frames_per_run": frames,
+    "units": {"FETCH_SIZE": "KB as reported; gfx950 tallies 128-B requests at 64 B, so bytes = 2 * 1024 * value",
+              "WRITE_SIZE": "KB, exact"},
+    "render_kernels_per_frame": {
+        "fetch_bytes_corrected": 2 * 1024 * fetch_kb / frames,
+        "write_bytes": 1024 * write_kb / frames,
+        "hbm_bytes": (2 * 1024 * fetch_kb + 1024 * write_kb) / frames,
+    },
+    "kernels": summary,
+}
+json.dump(doc, open(f"{out}_pmc.json", "w"), indent=1)
+print(json.dumps(doc["render_kernels_per_frame"]))
