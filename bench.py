@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pawn1080", choices=sorted(WORKLOADS))
     ap.add_argument("--pipeline", default="wavefront", choices=["megakernel", "wavefront"])
+    ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="host binned-SAH or device LBVH build")
     ap.add_argument("--cpu-pixels", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -136,7 +137,7 @@ def main():
 
     example, hs, vs, ntris, desc = WORKLOADS[args.workload]
     pipeline = {"megakernel": rt.PIPELINE_MEGAKERNEL, "wavefront": rt.PIPELINE_WAVEFRONT}[args.pipeline]
-    w = rt.World.example(example, hs, vs, synthetic_tris=ntris).commit(device=dev.index)
+    w = rt.World.example(example, hs, vs, synthetic_tris=ntris).commit(device=dev.index, bvh_builder=1 if args.bvh == "lbvh" else 0)
     info = w.info()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -222,7 +223,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "hsize": hs, "vsize": vs, "depth": 5, "mode": "f64_parity",
-                       "pipeline": args.pipeline, "rays_per_frame": rays_per_frame,
+                       "pipeline": args.pipeline, "bvh": args.bvh, "commit_ms": info["commit_ms"], "rays_per_frame": rays_per_frame,
                        "parallelism": f"tiles{rt.TILE}x{rt.TILE} round-robin over {n} GPU(s)" + (", RCCL gather to rank 0" if n > 1 else ""),
                        "triangles": info["n_triangles"], "bvh_nodes": info["n_bvh_nodes"],
                        "scene_bytes": info["device_bytes"], "frame_crc32": frame_crc},

@@ -5,6 +5,7 @@
 // would have hit.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "rt_layout.h"
@@ -23,6 +24,11 @@ struct BuildResult {
 // p1,p2,p3: n x 3 doubles.  max_leaf: triangles per leaf (<= 7).
 void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, int max_leaf,
                BuildResult& out);
+
+// The same result built on the current HIP device (Morton codes, radix sort, Karras' radix
+// tree, bottom-up refit): host arrays in, host vectors out.  Returns 0, or 1 with `err` set.
+int build_lbvh_device(const double* p1, const double* p2, const double* p3, int64_t n, int max_leaf,
+                      BuildResult& out, std::string& err);
 
 // Relative padding applied to every box, times the largest |coordinate| of the mesh.
 constexpr double BOX_PAD_REL = 1e-7;

@@ -610,7 +610,7 @@ int rt_scene_add_light(rt_scene* s, const double intensity[3], const double posi
 int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   if (!s) return fail(RT_ERR_ARG, "null scene");
   if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
-  if (bvh_builder != 0) return fail(RT_ERR_UNSUPPORTED, "only the host SAH builder (0) is built");
+  if (bvh_builder != 0 && bvh_builder != 1) return fail(RT_ERR_ARG, "bvh_builder must be 0 (host SAH) or 1 (device LBVH)");
   int ndev = rt_device_count();
   if (ndev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible; the render core has no CPU path");
   if (device < 0) HIP_TRY(hipGetDevice(&device));
@@ -681,7 +681,13 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     rtb::BuildResult br;
     int max_leaf = 6;
     if (const char* e = getenv("RT_MAX_LEAF")) max_leaf = atoi(e);
-    rtb::build_sah(h.p1.data(), h.p2.data(), h.p3.data(), h.ntris, max_leaf, br);
+    if (bvh_builder == 1) {
+      std::string berr;
+      if (rtb::build_lbvh_device(h.p1.data(), h.p2.data(), h.p3.data(), h.ntris, max_leaf, br, berr))
+        return fail(RT_ERR_HIP, "device BVH build: " + berr);
+    } else {
+      rtb::build_sah(h.p1.data(), h.p2.data(), h.p3.data(), h.ntris, max_leaf, br);
+    }
     if (br.max_depth >= STACK_MAX - 2)
       return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     DMesh& M = meshes[mi];

@@ -1,0 +1,430 @@
+// rt_lbvh.hip — BVH construction on the GPU for one triangle mesh (object space).
+//
+// Replaces the bounding-box tree of shapes/group.rs (the reference has none for its flat
+// child list, group.rs:64-71) with a linear BVH:
+//   triangle boxes + mesh bounds  ->  30-bit Morton code of each centroid
+//   ->  radix sort of (code << 32 | face)  ->  Karras' radix tree over the sorted keys
+//   ->  bottom-up refit  ->  collapse of subtrees with <= max_leaf triangles into leaves
+//   ->  nodes in the 32-byte layout of rt_layout.h (both children's boxes on the mesh's
+//       16-bit grid, rounded outward).
+// Like the host builder it produces a pure culling structure; which triangle a ray hits is
+// decided by the exact test in rt_device.h.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_bvh.h"
+
+namespace rtb {
+namespace {
+
+#define LB_TRY(expr)                                                        \
+  do {                                                                      \
+    hipError_t e_ = (expr);                                                 \
+    if (e_ != hipSuccess) {                                                 \
+      err = std::string(#expr) + ": " + hipGetErrorString(e_);              \
+      return 1;                                                             \
+    }                                                                       \
+  } while (0)
+
+struct Box6 {
+  double lo[3], hi[3];
+};
+// reduction cell: order-preserving integer images of doubles, so integer atomics give min/max
+struct Bounds {
+  unsigned long long lo[3], hi[3], scale;
+};
+__host__ __device__ inline unsigned long long enc(double x) {
+  unsigned long long b;
+  memcpy(&b, &x, 8);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ __device__ inline double dec(unsigned long long e) {
+  unsigned long long b = (e >> 63) ? (e & 0x7fffffffffffffffull) : ~e;
+  double x;
+  memcpy(&x, &b, 8);
+  return x;
+}
+
+__device__ inline double wave_min(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ inline double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__global__ void k_tri_bounds(const double* p1, const double* p2, const double* p3, int n, Box6* boxes,
+                             Bounds* bounds) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const double inf = __builtin_huge_val();
+  double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, sc = 0.0;
+  if (t < n) {
+    Box6 b;
+    for (int a = 0; a < 3; a++) {
+      double x = p1[3 * t + a], y = p2[3 * t + a], z = p3[3 * t + a];
+      b.lo[a] = fmin(fmin(x, y), z);
+      b.hi[a] = fmax(fmax(x, y), z);
+      lo[a] = b.lo[a];
+      hi[a] = b.hi[a];
+      sc = fmax(sc, fmax(fabs(b.lo[a]), fabs(b.hi[a])));
+    }
+    boxes[t] = b;
+  }
+  for (int a = 0; a < 3; a++) {
+    lo[a] = wave_min(lo[a]);
+    hi[a] = wave_max(hi[a]);
+  }
+  sc = wave_max(sc);
+  if ((threadIdx.x & 63) == 0) {
+    for (int a = 0; a < 3; a++) {
+      atomicMin(&bounds->lo[a], enc(lo[a]));
+      atomicMax(&bounds->hi[a], enc(hi[a]));
+    }
+    atomicMax(&bounds->scale, enc(sc));
+  }
+}
+
+__device__ inline unsigned expand10(unsigned v) {  // 10 bits -> every third bit
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+__global__ void k_morton(const Box6* boxes, int n, const Bounds* bounds, unsigned long long* keys) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  unsigned q[3];
+  for (int a = 0; a < 3; a++) {
+    double lo = dec(bounds->lo[a]), hi = dec(bounds->hi[a]);
+    double c = 0.5 * (boxes[t].lo[a] + boxes[t].hi[a]);
+    double ext = hi - lo;
+    double x = ext > 0.0 ? (c - lo) / ext : 0.0;
+    int v = (int)(x * 1024.0);
+    q[a] = (unsigned)min(max(v, 0), 1023);
+  }
+  unsigned code = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+  keys[t] = ((unsigned long long)code << 32) | (unsigned)t;
+}
+
+constexpr int LEAF_BIT = 0x40000000;
+
+// Karras 2012: internal node i of the radix tree over n sorted, distinct keys.
+__global__ void k_radix_tree(const unsigned long long* keys, int n, int* child_l, int* child_r,
+                             int* range_first, int* range_last, int* parent_inner, int* parent_leaf) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  auto delta = [&](int a, int b) -> int {
+    if (b < 0 || b >= n) return -1;
+    return __clzll((long long)(keys[a] ^ keys[b]));
+  };
+  int d = (delta(i, i + 1) - delta(i, i - 1)) >= 0 ? 1 : -1;
+  int dmin = delta(i, i - d);
+  int lmax = 2;
+  while (delta(i, i + lmax * d) > dmin) lmax *= 2;
+  int l = 0;
+  for (int t = lmax / 2; t >= 1; t /= 2)
+    if (delta(i, i + (l + t) * d) > dmin) l += t;
+  int j = i + l * d;
+  int dnode = delta(i, j);
+  int s = 0;
+  int t = l;
+  do {
+    t = (t + 1) / 2;
+    if (delta(i, i + (s + t) * d) > dnode) s += t;
+  } while (t > 1);
+  int gamma = i + s * d + min(d, 0);
+  int first = min(i, j), last = max(i, j);
+  range_first[i] = first;
+  range_last[i] = last;
+  if (first == gamma) {
+    child_l[i] = gamma | LEAF_BIT;
+    parent_leaf[gamma] = i;
+  } else {
+    child_l[i] = gamma;
+    parent_inner[gamma] = i;
+  }
+  if (last == gamma + 1) {
+    child_r[i] = (gamma + 1) | LEAF_BIT;
+    parent_leaf[gamma + 1] = i;
+  } else {
+    child_r[i] = gamma + 1;
+    parent_inner[gamma + 1] = i;
+  }
+  if (i == 0) parent_inner[0] = -1;
+}
+
+// Node boxes travel between workgroups: written and read with agent-scope atomics (a plain
+// load could be served from this CU's L1, which other CUs' stores never refresh).
+__device__ inline void box_store(double* dst, const double* src) {
+  for (int k = 0; k < 6; k++) __hip_atomic_store(dst + k, src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void box_load(const double* src, double* dst) {
+  for (int k = 0; k < 6; k++)
+    dst[k] = __hip_atomic_load(const_cast<double*>(src) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One thread per leaf walks towards the root; the second thread to reach a node owns it.
+__global__ void k_refit(const unsigned long long* keys, const Box6* tri_boxes, int n, const int* child_l,
+                        const int* child_r, const int* parent_inner, const int* parent_leaf,
+                        unsigned int* arrivals, double* node_boxes, int* node_depth) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int node = parent_leaf[k];
+  while (node >= 0) {
+    __threadfence();
+    unsigned prev = __hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == 0) return;
+    __threadfence();
+    double b[6] = {__builtin_huge_val(), __builtin_huge_val(), __builtin_huge_val(),
+                   -__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val()};
+    int depth = 0;
+    const int cs[2] = {child_l[node], child_r[node]};
+    for (int w = 0; w < 2; w++) {
+      double cb[6];
+      int cd = 0;
+      if (cs[w] & LEAF_BIT) {
+        const Box6& tb = tri_boxes[(unsigned)(keys[cs[w] & ~LEAF_BIT] & 0xffffffffull)];
+        for (int a = 0; a < 3; a++) {
+          cb[a] = tb.lo[a];
+          cb[3 + a] = tb.hi[a];
+        }
+      } else {
+        box_load(node_boxes + 6 * (size_t)cs[w], cb);
+        cd = __hip_atomic_load(node_depth + cs[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      for (int a = 0; a < 3; a++) {
+        b[a] = fmin(b[a], cb[a]);
+        b[3 + a] = fmax(b[3 + a], cb[3 + a]);
+      }
+      depth = max(depth, cd);
+    }
+    box_store(node_boxes + 6 * (size_t)node, b);
+    __hip_atomic_store(node_depth + node, depth + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    node = parent_inner[node];
+  }
+}
+
+__global__ void k_mark_live(const int* range_first, const int* range_last, int n_inner, int max_leaf,
+                            int* live) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_inner) return;
+  live[i] = (i == 0 || (range_last[i] - range_first[i] + 1) > max_leaf) ? 1 : 0;
+}
+
+struct GridD {
+  double base[3], cell[3], pad;
+};
+__device__ inline unsigned grid_down(const GridD& G, int a, double x) {
+  if (!(G.cell[a] > 0.0)) return 0;
+  double q = floor((x - G.base[a]) / G.cell[a]);
+  if (!(q > 0.0)) return 0;
+  if (q > 65535.0) q = 65535.0;
+  unsigned k = (unsigned)q;
+  while (k > 0 && G.base[a] + k * G.cell[a] > x) k--;
+  return k;
+}
+__device__ inline unsigned grid_up(const GridD& G, int a, double x) {
+  if (!(G.cell[a] > 0.0)) return 65535;
+  double q = ceil((x - G.base[a]) / G.cell[a]);
+  if (!(q > 0.0)) q = 0.0;
+  if (q > 65535.0) return 65535;
+  unsigned k = (unsigned)q;
+  while (k < 65535 && G.base[a] + k * G.cell[a] < x) k++;
+  return k;
+}
+
+__global__ void k_emit_nodes(const unsigned long long* keys, const Box6* tri_boxes, const int* child_l,
+                             const int* child_r, const int* range_first, const int* range_last,
+                             const double* node_boxes, const int* live, const int* new_index,
+                             int n_inner, int max_leaf, GridD G, rtd::DNode* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_inner || !live[i]) return;
+  rtd::DNode N;
+  const int cs[2] = {child_l[i], child_r[i]};
+  for (int w = 0; w < 2; w++) {
+    double b[6];
+    int code;
+    if (cs[w] & LEAF_BIT) {
+      int pos = cs[w] & ~LEAF_BIT;
+      const Box6& tb = tri_boxes[(unsigned)(keys[pos] & 0xffffffffull)];
+      for (int a = 0; a < 3; a++) {
+        b[a] = tb.lo[a];
+        b[3 + a] = tb.hi[a];
+      }
+      code = -2 - ((pos << 3) | 1);
+    } else {
+      int c = cs[w];
+      for (int k = 0; k < 6; k++) b[k] = node_boxes[6 * (size_t)c + k];
+      int cnt = range_last[c] - range_first[c] + 1;
+      code = (cnt <= max_leaf) ? -2 - ((range_first[c] << 3) | cnt) : new_index[c];
+    }
+    for (int a = 0; a < 3; a++) {
+      unsigned lo = grid_down(G, a, b[a] - G.pad), hi = grid_up(G, a, b[3 + a] + G.pad);
+      N.q[3 * w + a] = lo | (hi << 16);
+    }
+    (w == 0 ? N.c0 : N.c1) = code;
+  }
+  out[new_index[i]] = N;
+}
+
+__global__ void k_extract_order(const unsigned long long* keys, int n, uint32_t* order) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) order[i] = (uint32_t)(keys[i] & 0xffffffffull);
+}
+
+struct Scratch {  // frees what it holds when the build ends, whichever way
+  std::vector<void*> ptrs;
+  ~Scratch() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+  template <typename T>
+  hipError_t get(T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) ptrs.push_back(q);
+    *p = static_cast<T*>(q);
+    return e;
+  }
+};
+
+}  // namespace
+
+int build_lbvh_device(const double* p1, const double* p2, const double* p3, int64_t n64, int max_leaf,
+                      BuildResult& out, std::string& err) {
+  out.nodes.clear();
+  out.order.clear();
+  out.max_depth = 0;
+  out.scale = 0.0;
+  for (int a = 0; a < 3; a++) out.lo[a] = out.hi[a] = out.cell[a] = 0.0;
+  max_leaf = std::max(1, std::min(max_leaf, 7));
+  if (n64 > (1 << 28)) {
+    err = "mesh too large for the device builder";
+    return 1;
+  }
+  const int n = (int)n64;
+  rtd::DNode empty{};
+  for (int k = 0; k < 6; k++) empty.q[k] = 0xffffu;
+  empty.c0 = empty.c1 = -1;
+  if (n == 0) {
+    out.nodes.push_back(empty);
+    return 0;
+  }
+  Scratch S;
+  double *d1, *d2, *d3;
+  Box6* boxes;
+  Bounds* bounds;
+  unsigned long long *keys_in, *keys;
+  LB_TRY(S.get(&d1, 3 * (size_t)n));
+  LB_TRY(S.get(&d2, 3 * (size_t)n));
+  LB_TRY(S.get(&d3, 3 * (size_t)n));
+  LB_TRY(S.get(&boxes, (size_t)n));
+  LB_TRY(S.get(&bounds, 1));
+  LB_TRY(S.get(&keys_in, (size_t)n));
+  LB_TRY(S.get(&keys, (size_t)n));
+  LB_TRY(hipMemcpy(d1, p1, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  LB_TRY(hipMemcpy(d2, p2, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  LB_TRY(hipMemcpy(d3, p3, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  Bounds init;
+  const double inf = std::numeric_limits<double>::infinity();
+  for (int a = 0; a < 3; a++) {
+    init.lo[a] = enc(inf);
+    init.hi[a] = enc(-inf);
+  }
+  init.scale = enc(0.0);
+  LB_TRY(hipMemcpy(bounds, &init, sizeof init, hipMemcpyHostToDevice));
+  const dim3 block(256), grid((unsigned)((n + 255) / 256));
+  hipLaunchKernelGGL(k_tri_bounds, grid, block, 0, 0, d1, d2, d3, n, boxes, bounds);
+  hipLaunchKernelGGL(k_morton, grid, block, 0, 0, boxes, n, bounds, keys_in);
+  LB_TRY(hipGetLastError());
+  size_t temp_bytes = 0;
+  LB_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys_in, keys, n, 0, 62));
+  char* temp;
+  LB_TRY(S.get(&temp, temp_bytes));
+  LB_TRY(hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys_in, keys, n, 0, 62));
+
+  Bounds hb;
+  LB_TRY(hipMemcpy(&hb, bounds, sizeof hb, hipMemcpyDeviceToHost));
+  out.scale = dec(hb.scale);
+  const double pad = out.scale * BOX_PAD_REL + 1e-300;
+  GridD G;
+  G.pad = pad;
+  for (int a = 0; a < 3; a++) {
+    double lo = dec(hb.lo[a]) - 2.0 * pad, hi = dec(hb.hi[a]) + 2.0 * pad;
+    G.base[a] = lo;
+    G.cell[a] = (hi - lo) / 65535.0 * (1.0 + 1e-12);
+    out.lo[a] = lo;
+    out.hi[a] = std::max(hi, lo + 65535.0 * G.cell[a]);
+    out.cell[a] = G.cell[a];
+  }
+  uint32_t* d_order;
+  LB_TRY(S.get(&d_order, (size_t)n));
+  hipLaunchKernelGGL(k_extract_order, grid, block, 0, 0, keys, n, d_order);
+  out.order.resize((size_t)n);
+  LB_TRY(hipMemcpy(out.order.data(), d_order, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+
+  if (n <= max_leaf) {  // the whole mesh is one leaf
+    rtd::DNode N = empty;
+    for (int a = 0; a < 3; a++) N.q[a] = 0u | (65535u << 16);
+    N.c0 = -2 - ((0 << 3) | n);
+    out.nodes.push_back(N);
+    out.max_depth = 1;
+    return 0;
+  }
+
+  const int n_inner = n - 1;
+  int *child_l, *child_r, *range_first, *range_last, *parent_inner, *parent_leaf, *node_depth, *live,
+      *new_index;
+  unsigned int* arrivals;
+  double* node_boxes;
+  LB_TRY(S.get(&child_l, (size_t)n_inner));
+  LB_TRY(S.get(&child_r, (size_t)n_inner));
+  LB_TRY(S.get(&range_first, (size_t)n_inner));
+  LB_TRY(S.get(&range_last, (size_t)n_inner));
+  LB_TRY(S.get(&parent_inner, (size_t)n_inner));
+  LB_TRY(S.get(&parent_leaf, (size_t)n));
+  LB_TRY(S.get(&node_depth, (size_t)n_inner));
+  LB_TRY(S.get(&live, (size_t)n_inner));
+  LB_TRY(S.get(&new_index, (size_t)n_inner));
+  LB_TRY(S.get(&arrivals, (size_t)n_inner));
+  LB_TRY(S.get(&node_boxes, 6 * (size_t)n_inner));
+  LB_TRY(hipMemset(arrivals, 0, (size_t)n_inner * sizeof(unsigned int)));
+  LB_TRY(hipMemset(node_depth, 0, (size_t)n_inner * sizeof(int)));
+  const dim3 igrid((unsigned)((n_inner + 255) / 256));
+  hipLaunchKernelGGL(k_radix_tree, igrid, block, 0, 0, keys, n, child_l, child_r, range_first, range_last,
+                     parent_inner, parent_leaf);
+  hipLaunchKernelGGL(k_refit, grid, block, 0, 0, keys, boxes, n, child_l, child_r, parent_inner, parent_leaf,
+                     arrivals, node_boxes, node_depth);
+  hipLaunchKernelGGL(k_mark_live, igrid, block, 0, 0, range_first, range_last, n_inner, max_leaf, live);
+  LB_TRY(hipGetLastError());
+  size_t scan_bytes = 0;
+  LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, live, new_index, n_inner));
+  char* scan_temp;
+  LB_TRY(S.get(&scan_temp, scan_bytes));
+  LB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_temp, scan_bytes, live, new_index, n_inner));
+  int last_live = 0, last_index = 0, root_depth = 0;
+  LB_TRY(hipMemcpy(&last_live, live + n_inner - 1, sizeof(int), hipMemcpyDeviceToHost));
+  LB_TRY(hipMemcpy(&last_index, new_index + n_inner - 1, sizeof(int), hipMemcpyDeviceToHost));
+  LB_TRY(hipMemcpy(&root_depth, node_depth, sizeof(int), hipMemcpyDeviceToHost));
+  const int n_live = last_index + last_live;
+  rtd::DNode* d_nodes;
+  LB_TRY(S.get(&d_nodes, (size_t)n_live));
+  hipLaunchKernelGGL(k_emit_nodes, igrid, block, 0, 0, keys, boxes, child_l, child_r, range_first, range_last,
+                     node_boxes, live, new_index, n_inner, max_leaf, G, d_nodes);
+  LB_TRY(hipGetLastError());
+  out.nodes.resize((size_t)n_live);
+  LB_TRY(hipMemcpy(out.nodes.data(), d_nodes, (size_t)n_live * sizeof(rtd::DNode), hipMemcpyDeviceToHost));
+  out.max_depth = root_depth;
+  return 0;
+}
+
+}  // namespace rtb

@@ -152,6 +152,25 @@ def test_pawn_8k_sample(rt, O, pipeline):
     assert st.rays_primary == 7680 * 4320
 
 
+@pytest.mark.parametrize("name,size,ntris", [("pawn", (480, 270), 0), ("tea set", (480, 270), 0),
+                                             ("synthetic", (320, 180), 50000)])
+def test_device_built_bvh(rt, O, name, size, ntris):
+    """bvh_builder=1 (Morton codes, radix sort, Karras tree and refit on the GPU): the
+    hierarchy only culls, so the frame must be the same bits as with the host SAH build,
+    and equal to the oracle."""
+    a = rt.World.example(name, *size, synthetic_tris=ntris).commit(bvh_builder=0)
+    b = rt.World.example(name, *size, synthetic_tris=ntris).commit(bvh_builder=1)
+    assert b.info()["bvh_builder"] == 1 and b.info()["n_bvh_nodes"] > 0
+    ua, fa, _ = a.render(want_f64=True)
+    ub, fb, sb = b.render(want_f64=True, want_stats=True)
+    assert np.array_equal(fa, fb)
+    assert np.array_equal(ua, ub)
+    sc = O.Scene.example(name, *size, synthetic_tris=ntris).use_bvh()
+    _, ou8, cnt = sc.render()
+    assert np.array_equal(ub, ou8)
+    assert sb.rays_shadow == cnt["shadow"]
+
+
 # ---- random and adversarial scenes -------------------------------------------------------------
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_scenes(rt, O, seed):
