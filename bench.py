@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pawn1080", choices=sorted(WORKLOADS))
     ap.add_argument("--pipeline", default="wavefront", choices=["megakernel", "wavefront"])
+    ap.add_argument("--mode", default="f64_parity", choices=["f64_parity", "f32_fast"],
+                    help="f32_fast: triangle search in f32, everything else f64; reported with its pixel-match rate")
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="host binned-SAH or device LBVH build")
     ap.add_argument("--cpu-pixels", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -137,6 +139,7 @@ def main():
 
     example, hs, vs, ntris, desc = WORKLOADS[args.workload]
     pipeline = {"megakernel": rt.PIPELINE_MEGAKERNEL, "wavefront": rt.PIPELINE_WAVEFRONT}[args.pipeline]
+    mode = rt.MODE_F32_FAST if args.mode == "f32_fast" else rt.MODE_F64_PARITY
     w = rt.World.example(example, hs, vs, synthetic_tris=ntris).commit(device=dev.index, bvh_builder=1 if args.bvh == "lbvh" else 0)
     info = w.info()
     stream = torch.cuda.current_stream().cuda_stream
@@ -163,9 +166,9 @@ def main():
 
     def step(want_stats=False):
         if n == 1:
-            w.render_device(d_u8=image.data_ptr(), stream=stream, pipeline=pipeline, want_stats=want_stats)
+            w.render_device(d_u8=image.data_ptr(), stream=stream, pipeline=pipeline, mode=mode, want_stats=want_stats)
         else:
-            w.render_device(d_u8=tiles.data_ptr(), stream=stream, pipeline=pipeline, tile_first=rank,
+            w.render_device(d_u8=tiles.data_ptr(), stream=stream, pipeline=pipeline, mode=mode, tile_first=rank,
                             tile_step=n, want_stats=want_stats)
             exchange()
 
@@ -194,7 +197,7 @@ def main():
             step()
             ev[i][1].record()
         else:
-            w.render_device(d_u8=tiles.data_ptr(), stream=stream, pipeline=pipeline, tile_first=rank, tile_step=n)
+            w.render_device(d_u8=tiles.data_ptr(), stream=stream, pipeline=pipeline, mode=mode, tile_first=rank, tile_step=n)
             ev[i][1].record()
             exchange()
     torch.cuda.synchronize()
@@ -221,8 +224,9 @@ def main():
                       else f"Mrays/s (primary+shadow+reflection+refraction), {args.workload}",
             "value": value, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc, "hsize": hs, "vsize": vs, "depth": 5, "mode": "f64_parity",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if args.mode == "f64_parity" else "f32 triangle search + f64 shading", "data": "synthetic",
+            "config": {"workload": desc, "hsize": hs, "vsize": vs, "depth": 5, "mode": args.mode,
                        "pipeline": args.pipeline, "bvh": args.bvh, "commit_ms": info["commit_ms"], "rays_per_frame": rays_per_frame,
                        "parallelism": f"tiles{rt.TILE}x{rt.TILE} round-robin over {n} GPU(s)" + (", RCCL gather to rank 0" if n > 1 else ""),
                        "triangles": info["n_triangles"], "bvh_nodes": info["n_bvh_nodes"],
@@ -241,6 +245,14 @@ def main():
                                   "algorithmic_flops_per_launch": aflops / n},
             "counters_per_frame": {k: st[k] for k in keys},
         }
+        if args.mode == "f32_fast" and n == 1:
+            # the fast mode is reported with its pixel-match rate against the parity mode's frame
+            fast = image.cpu().numpy().astype(np.int16)
+            w.render_device(d_u8=image.data_ptr(), stream=stream, pipeline=pipeline, mode=rt.MODE_F64_PARITY)
+            torch.cuda.synchronize()
+            d = np.abs(fast - image.cpu().numpy().astype(np.int16)).max(axis=-1)
+            out["pixel_match_vs_f64_parity"] = {"exact": float((d == 0).mean()), "within_1": float((d <= 1).mean()),
+                                                "worst": int(d.max()), "pixels": int(d.size)}
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(example, hs, vs, ntris, args.cpu_pixels)
         print(json.dumps(out), flush=True)

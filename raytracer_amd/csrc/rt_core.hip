@@ -323,7 +323,7 @@ constexpr int WF_BLOCK = 64;
 #ifndef WF_WAVES
 #define WF_WAVES 4
 #endif
-template <bool STATS, bool PRIMARY>
+template <bool STATS, bool PRIMARY, bool FAST>
 __global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
 k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n, long long n_front,
            unsigned int cap, WfNode* nodes, WfTask* next, unsigned int* next_count,
@@ -366,9 +366,9 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
   }
   if (active) {
     HitRec h;
-    if (trace_closest<STATS>(S, ray, h, cnt, st)) {
+    if (trace_closest<STATS, FAST>(S, ray, h, cnt, st)) {
       ShadeOut so;
-      shade_hit_local<STATS>(S, ray, h, so, cnt, st);
+      shade_hit_local<STATS, FAST>(S, ray, h, so, cnt, st);
       nd.surface[0] = so.surface.r;
       nd.surface[1] = so.surface.g;
       nd.surface[2] = so.surface.b;
@@ -669,6 +669,7 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   // meshes: edges (triangle.rs:49-51), BVH, records in leaf order
   std::vector<DMesh> meshes(s->meshes.size());
   std::vector<DTri> tris;
+  std::vector<DTriF> trisf;
   std::vector<DTriN> trin;
   std::vector<DNode> nodes;
   int64_t total_tris = 0;
@@ -740,7 +741,17 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
         TN.n[2] = cz / mag;
         for (int a = 3; a < 9; a++) TN.n[a] = 0.0;
       }
+      DTriF TF;
+      for (int a = 0; a < 3; a++) {
+        TF.p1[a] = (float)T.p1[a];
+        TF.e1[a] = (float)T.e1[a];
+        TF.e2[a] = (float)T.e2[a];
+      }
+      TF.orig = T.orig;
+      TF.smooth = T.smooth;
+      TF.pad = 0;
       tris.push_back(T);
+      trisf.push_back(TF);
       trin.push_back(TN);
     }
   }
@@ -752,6 +763,7 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   if ((rc = upload(s, prim_boxes, &s->d.prim_boxes))) return rc;
   if ((rc = upload(s, meshes, &s->d.meshes))) return rc;
   if ((rc = upload(s, tris, &s->d.tris))) return rc;
+  if ((rc = upload(s, trisf, &s->d.trisf))) return rc;
   if ((rc = upload(s, trin, &s->d.trin))) return rc;
   if ((rc = upload(s, nodes, &s->d.nodes))) return rc;
   if ((rc = upload(s, mats, &s->d.mats))) return rc;
@@ -824,7 +836,8 @@ static int wf_ensure(void** p, size_t* cap, size_t need, size_t elem) {
 }
 
 static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, int64_t ntiles,
-                            int depth, double* d_f64, uint8_t* d_u8, hipStream_t st, bool stats) {
+                            int depth, double* d_f64, uint8_t* d_u8, hipStream_t st, bool stats,
+                            bool fast) {
   if (!s->wf_counts) {
     HIP_TRY(hipMalloc(&s->wf_counts, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int)));
     HIP_TRY(hipHostMalloc(&s->wf_counts_host, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int)));
@@ -850,14 +863,22 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     WfTask* tnext = spawn ? static_cast<WfTask*>(s->wf_tasks[l + 1]) : nullptr;
     unsigned int cap = spawn ? (unsigned int)std::min<size_t>(s->wf_task_cap[l + 1], 0xffffffffu) : 0u;
     unsigned int* cnt_next = s->wf_counts + 2 * (l + 1);
-#define WF_LAUNCH(ST, PR)                                                                        \
-  hipLaunchKernelGGL((k_wf_level<ST, PR>), grid, block, 0, st, s->d, dc, pm, tin, n, n_front, cap_in, \
+#define WF_LAUNCH(ST, PR, FA)                                                                        \
+  hipLaunchKernelGGL((k_wf_level<ST, PR, FA>), grid, block, 0, st, s->d, dc, pm, tin, n, n_front, cap_in, \
                      nodes, tnext, cnt_next, cap, spawn ? 1 : 0, s->d_counters)
+#define WF_LAUNCH2(ST, PR) \
+  do {                     \
+    if (fast)              \
+      WF_LAUNCH(ST, PR, true); \
+    else                   \
+      WF_LAUNCH(ST, PR, false); \
+  } while (0)
     if (l == 0) {
-      if (stats) WF_LAUNCH(true, true); else WF_LAUNCH(false, true);
+      if (stats) WF_LAUNCH2(true, true); else WF_LAUNCH2(false, true);
     } else {
-      if (stats) WF_LAUNCH(true, false); else WF_LAUNCH(false, false);
+      if (stats) WF_LAUNCH2(true, false); else WF_LAUNCH2(false, false);
     }
+#undef WF_LAUNCH2
 #undef WF_LAUNCH
     HIP_TRY(hipGetLastError());
     s->launches++;
@@ -892,7 +913,11 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, int depth, int mode, int
                      void* hip_stream, int want_stats) {
   if (!s || !cam) return fail(RT_ERR_ARG, "null argument");
   if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
-  if (mode != RT_MODE_F64_PARITY) return fail(RT_ERR_UNSUPPORTED, "only RT_MODE_F64_PARITY is built");
+  if (mode != RT_MODE_F64_PARITY && mode != RT_MODE_F32_FAST) return fail(RT_ERR_ARG, "unknown mode");
+  if (mode == RT_MODE_F32_FAST && pipeline != RT_PIPELINE_WAVEFRONT)
+    return fail(RT_ERR_UNSUPPORTED, "RT_MODE_F32_FAST runs on the wavefront pipeline only");
+  if (mode == RT_MODE_F32_FAST && depth == 0)
+    return fail(RT_ERR_UNSUPPORTED, "RT_MODE_F32_FAST needs depth >= 1");
   if (pipeline != RT_PIPELINE_MEGAKERNEL && pipeline != RT_PIPELINE_WAVEFRONT)
     return fail(RT_ERR_ARG, "unknown pipeline");
   if (depth < 0 || depth > MAX_DEPTH) return fail(RT_ERR_ARG, "depth out of range (0..8)");
@@ -914,7 +939,8 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, int depth, int mode, int
   HIP_TRY(hipEventRecord(s->ev0, st));
   s->launches = 0;
   if (ntiles > 0 && pipeline == RT_PIPELINE_WAVEFRONT && depth > 0) {
-    rc = render_wavefront(s, dc, pm, ntiles, depth, d_rgb_f64, d_rgb_u8, st, want_stats != 0);
+    rc = render_wavefront(s, dc, pm, ntiles, depth, d_rgb_f64, d_rgb_u8, st, want_stats != 0,
+                          mode == RT_MODE_F32_FAST);
     if (rc) return rc;
   } else if (ntiles > 0) {
     constexpr int PATCHES = (RT_TILE / 8) * (RT_TILE / 8);

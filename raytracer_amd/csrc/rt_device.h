@@ -125,6 +125,31 @@ __device__ __forceinline__ bool moller_trumbore(const DTri& T, const Ray& r, dou
   return true;
 }
 
+// The same test in f32 (fast arithmetic mode): candidates are found with it, the winner is
+// evaluated again in f64.
+struct RayF {
+  float ox, oy, oz, dx, dy, dz;
+};
+__device__ __forceinline__ bool moller_trumbore_f32(const DTriF& T, const RayF& r, float& t, float& u,
+                                                    float& v) {
+  float cx = r.dy * T.e2[2] - r.dz * T.e2[1];
+  float cy = r.dz * T.e2[0] - r.dx * T.e2[2];
+  float cz = r.dx * T.e2[1] - r.dy * T.e2[0];
+  float det = T.e1[0] * cx + T.e1[1] * cy + T.e1[2] * cz;
+  if (fabsf(det) < (float)EPS) return false;
+  float f = 1.0f / det;
+  float px = r.ox - T.p1[0], py = r.oy - T.p1[1], pz = r.oz - T.p1[2];
+  u = f * (px * cx + py * cy + pz * cz);
+  if (!(u >= 0.0f && u <= 1.0f)) return false;
+  float qx = py * T.e1[2] - pz * T.e1[1];
+  float qy = pz * T.e1[0] - px * T.e1[2];
+  float qz = px * T.e1[1] - py * T.e1[0];
+  v = f * (r.dx * qx + r.dy * qy + r.dz * qz);
+  if (v < 0.0f || (u + v) > 1.0f) return false;
+  t = f * (T.e2[0] * qx + T.e2[1] * qy + T.e2[2] * qz);
+  return true;
+}
+
 // f64::max / f64::min ignore a NaN operand (cube.rs:74-75, 85-92); so do fmax/fmin.
 __device__ __forceinline__ void cube_axis(double origin, double direction, double& tmin,
                                           double& tmax) {  // cube.rs:48-66
@@ -358,6 +383,28 @@ __device__ __forceinline__ void pin(TriRaw& r, TriRaw& s) {
                : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e), "+v"(s.a), "+v"(s.b),
                  "+v"(s.c), "+v"(s.d), "+v"(s.e));
 }
+struct TriRawF {
+  u32x4 a, b, c;
+};
+__device__ __forceinline__ TriRawF load_tri_raw(const DTriF* p) {
+  const u32x4* q = reinterpret_cast<const u32x4*>(p);
+  TriRawF r;
+  r.a = q[0]; r.b = q[1]; r.c = q[2];
+  return r;
+}
+__device__ __forceinline__ void pin(TriRawF& r, TriRawF& s) {
+  asm volatile("" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(s.a), "+v"(s.b), "+v"(s.c));
+}
+__device__ __forceinline__ DTriF decode_tri(const TriRawF& r) {
+  DTriF t;
+  t.p1[0] = __uint_as_float(r.a.x); t.p1[1] = __uint_as_float(r.a.y); t.p1[2] = __uint_as_float(r.a.z);
+  t.e1[0] = __uint_as_float(r.a.w); t.e1[1] = __uint_as_float(r.b.x); t.e1[2] = __uint_as_float(r.b.y);
+  t.e2[0] = __uint_as_float(r.b.z); t.e2[1] = __uint_as_float(r.b.w); t.e2[2] = __uint_as_float(r.c.x);
+  t.orig = r.c.y;
+  t.smooth = r.c.z;
+  t.pad = 0;
+  return t;
+}
 __device__ __forceinline__ DTri decode_tri(const TriRaw& r) {
   DTri t;
   t.p1[0] = __hiloint2double((int)r.a.y, (int)r.a.x);
@@ -518,16 +565,10 @@ struct Query {
   double u, v;
 };
 
-template <int MODE, bool STATS>
-__device__ __forceinline__ bool test_tri(const DTri& T, uint32_t order_base, int m, int rec,
-                                         const Ray& lr, Query& q, Counters& cnt) {
-  double t, u, v;
-  if (STATS) {
-    if (wave_leader()) cnt.tri_wave_steps++;
-    cnt.tri_tests++;
-  }
-  if (!moller_trumbore(T, lr, t, u, v)) return false;
-  uint32_t ord = order_base + T.orig;
+// Accepts one candidate intersection (t, u, v of triangle `rec`) into the query.
+template <int MODE>
+__device__ __forceinline__ bool accept_hit(double t, double u, double v, uint32_t ord, int m, int rec,
+                                           Query& q) {
   if (MODE == Q_CLOSEST) {
     if (t > 0.0 && (t < q.hi || (t == q.hi && ord < q.hi_order))) {
       q.hi = t;
@@ -541,6 +582,9 @@ __device__ __forceinline__ bool test_tri(const DTri& T, uint32_t order_base, int
   } else if (MODE == Q_ANY) {
     if (t > 0.0 && t < q.hi) return true;
   } else {
+    // q.tri: the record of the hit whose predecessor is sought.  In f64 its own entry equals
+    // the trigger key and is never below it; an f32 t of the same triangle could be.
+    if (rec == q.tri) return false;
     Key c{t, ord, 0};
     Key K{q.hi, q.hi_order, 0};
     if (key_less(c, K) && (!q.found || key_less(q.best, c))) {
@@ -551,27 +595,51 @@ __device__ __forceinline__ bool test_tri(const DTri& T, uint32_t order_base, int
   }
   return false;
 }
+template <int MODE, bool STATS>
+__device__ __forceinline__ bool test_tri(const DTri& T, uint32_t order_base, int m, int rec,
+                                         const Ray& lr, const RayF&, Query& q, Counters& cnt) {
+  double t, u, v;
+  if (STATS) {
+    if (wave_leader()) cnt.tri_wave_steps++;
+    cnt.tri_tests++;
+  }
+  if (!moller_trumbore(T, lr, t, u, v)) return false;
+  return accept_hit<MODE>(t, u, v, order_base + T.orig, m, rec, q);
+}
+template <int MODE, bool STATS>
+__device__ __forceinline__ bool test_tri(const DTriF& T, uint32_t order_base, int m, int rec,
+                                         const Ray&, const RayF& lrf, Query& q, Counters& cnt) {
+  float t, u, v;
+  if (STATS) {
+    if (wave_leader()) cnt.tri_wave_steps++;
+    cnt.tri_tests++;
+  }
+  if (!moller_trumbore_f32(T, lrf, t, u, v)) return false;
+  return accept_hit<MODE>((double)t, (double)u, (double)v, order_base + T.orig, m, rec, q);
+}
 
 // The triangles of one leaf, two at a time: both records are in flight together.  Which
 // triangle wins does not depend on the test order (the comparisons carry the leaf order).
-template <int MODE, bool STATS>
-__device__ __forceinline__ bool test_leaf(uint32_t order_base, int tri_base, int m, const DTri* tris,
-                                          int first, int count, const Ray& lr, Query& q,
-                                          Counters& cnt) {
+// TRI is DTri (f64 records) or DTriF (f32 records of the fast mode).
+template <int MODE, bool STATS, typename TRI>
+__device__ __forceinline__ bool test_leaf(uint32_t order_base, int tri_base, int m, const TRI* tris,
+                                          int first, int count, const Ray& lr, const RayF& lrf,
+                                          Query& q, Counters& cnt) {
   for (int k = 0; k < count; k += 2) {
     const bool two = k + 1 < count;
-    TriRaw r0 = load_tri_raw(tris + first + k);
-    TriRaw r1 = load_tri_raw(tris + first + (two ? k + 1 : k));
+    auto r0 = load_tri_raw(tris + first + k);
+    auto r1 = load_tri_raw(tris + first + (two ? k + 1 : k));
     pin(r0, r1);
-    if (test_tri<MODE, STATS>(decode_tri(r0), order_base, m, tri_base + first + k, lr, q, cnt)) return true;
-    if (two && test_tri<MODE, STATS>(decode_tri(r1), order_base, m, tri_base + first + k + 1, lr, q, cnt))
+    if (test_tri<MODE, STATS>(decode_tri(r0), order_base, m, tri_base + first + k, lr, lrf, q, cnt))
+      return true;
+    if (two && test_tri<MODE, STATS>(decode_tri(r1), order_base, m, tri_base + first + k + 1, lr, lrf, q, cnt))
       return true;
   }
   return false;
 }
 
 // Walks every mesh.  Returns true as soon as a Q_ANY query is satisfied.
-template <int MODE, bool STATS>
+template <int MODE, bool STATS, bool FAST>
 __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q, Counters& cnt,
                                        TravStack& st) {
   for (int m = 0; m < S.n_meshes; m++) {
@@ -583,6 +651,8 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
     const int tri_base = M.tri_base;
     const uint32_t order_base = M.order_base;
     const DTri* tris = S.tris + tri_base;
+    const DTriF* trisf = S.trisf + tri_base;
+    RayF lrf = {(float)lr.o.x, (float)lr.o.y, (float)lr.o.z, (float)lr.d.x, (float)lr.d.y, (float)lr.d.z};
     // query interval in t - t_base, rounded outward
     float qlo, qhi;
     if (MODE == Q_PRED) {
@@ -630,7 +700,9 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
       }
       if (cur != -1) {
         int code = -2 - cur;
-        if (test_leaf<MODE, STATS>(order_base, tri_base, m, tris, code >> 3, code & 7, lr, q, cnt)) return true;
+        const bool done = FAST ? test_leaf<MODE, STATS>(order_base, tri_base, m, trisf, code >> 3, code & 7, lr, lrf, q, cnt)
+                               : test_leaf<MODE, STATS>(order_base, tri_base, m, tris, code >> 3, code & 7, lr, lrf, q, cnt);
+        if (done) return true;
         // a leaf may have tightened the interval
         if (MODE == Q_CLOSEST) {
           if (q.hi < 1e300) qhi = f32_up(q.hi - c.t_base);
@@ -646,7 +718,7 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
 
 // hit() of intersect.rs:125-139 over the list of world.rs:22-32: smallest t > 0, the
 // earliest leaf among equal t.
-template <bool STATS>
+template <bool STATS, bool FAST = false>
 __device__ inline bool trace_closest(const DScene& S, const Ray& ray, HitRec& h, Counters& cnt,
                                      TravStack& st) {
   Query q;
@@ -677,7 +749,18 @@ __device__ inline bool trace_closest(const DScene& S, const Ray& ray, HitRec& h,
     }
   }
   int prim_before = q.mesh;  // stays -1 unless a triangle wins
-  traverse_meshes<Q_CLOSEST, STATS>(S, ray, q, cnt, st);
+  traverse_meshes<Q_CLOSEST, STATS, FAST>(S, ray, q, cnt, st);
+  if (FAST && q.mesh >= 0) {
+    // the f32 search picked the triangle; t, u, v of the pick in f64 when the f64 test agrees
+    const DMesh& M = S.meshes[q.mesh];
+    Ray lr = ray_to_group(S, M.group, ray);
+    double t, u, v;
+    if (moller_trumbore(S.tris[q.tri], lr, t, u, v) && t > 0.0) {
+      q.hi = t;
+      q.u = u;
+      q.v = v;
+    }
+  }
   (void)prim_before;
   h.t = q.hi;
   h.order = q.hi_order;
@@ -691,7 +774,7 @@ __device__ inline bool trace_closest(const DScene& S, const Ray& ray, HitRec& h,
 
 // is_shadowed (world.rs:116-134): the nearest positive hit is closer than `distance`
 // exactly when some intersection has 0 < t < distance.
-template <bool STATS>
+template <bool STATS, bool FAST = false>
 __device__ inline bool trace_any(const DScene& S, const Ray& ray, double distance, Counters& cnt,
                                  TravStack& st) {
   const BoxRay br = make_box_ray(ray);
@@ -711,22 +794,22 @@ __device__ inline bool trace_any(const DScene& S, const Ray& ray, double distanc
   q.found = false;
   q.mesh = -1;
   q.tri = -1;
-  return traverse_meshes<Q_ANY, STATS>(S, ray, q, cnt, st);
+  return traverse_meshes<Q_ANY, STATS, FAST>(S, ray, q, cnt, st);
 }
 
 // Largest key below K among all triangle intersections of the infinite line (t may be
 // negative).  Every triangle is its own shape with at most one entry, so this is the last
 // triangle still "open" when the containers walk of intersect.rs:188-222 reaches K.
-template <bool STATS>
-__device__ inline bool tri_predecessor(const DScene& S, const Ray& ray, const Key& K, Key& best,
-                                       int& best_mesh, Counters& cnt, TravStack& st) {
+template <bool STATS, bool FAST = false>
+__device__ inline bool tri_predecessor(const DScene& S, const Ray& ray, const Key& K, int own_tri,
+                                       Key& best, int& best_mesh, Counters& cnt, TravStack& st) {
   Query q;
   q.hi = K.t;
   q.hi_order = K.order;
   q.found = false;
   q.mesh = -1;
-  q.tri = -1;
-  traverse_meshes<Q_PRED, STATS>(S, ray, q, cnt, st);
+  q.tri = own_tri;
+  traverse_meshes<Q_PRED, STATS, FAST>(S, ray, q, cnt, st);
   if (q.found) {
     best = q.best;
     best_mesh = q.mesh;
@@ -829,7 +912,7 @@ __device__ inline void containers_from(const DScene& S, const Ray& ray, const Hi
     n2 = own_ri;  // the hit enters its own shape, which becomes the last container
 }
 
-template <bool STATS>
+template <bool STATS, bool FAST = false>
 __device__ inline void containers_n1_n2(const DScene& S, const Ray& ray, const HitRec& h,
                                         double own_ri, double& n1, double& n2, Counters& cnt,
                                         TravStack& st) {
@@ -837,7 +920,7 @@ __device__ inline void containers_n1_n2(const DScene& S, const Ray& ray, const H
   Key K = trigger_key(S, ray, h);
   Key tb{0.0, 0u, 0};
   int tm = -1;
-  bool tf = (S.n_meshes > 0) && tri_predecessor<STATS>(S, ray, K, tb, tm, cnt, st);
+  bool tf = (S.n_meshes > 0) && tri_predecessor<STATS, FAST>(S, ray, K, h.prim >= 0 ? -1 : h.tri, tb, tm, cnt, st);
   containers_from<STATS>(S, ray, h, K, own_ri, tf, tb, tm, n1, n2, cnt);
 }
 
@@ -1029,7 +1112,7 @@ __device__ inline void finish_optics(const DMaterial& M, const Ray& ray, const P
 }
 
 // prepare_computations + the light loop of shade_hit + the child-ray set-up, in one lane.
-template <bool STATS>
+template <bool STATS, bool FAST = false>
 __device__ inline void shade_hit_local(const DScene& S, const Ray& ray, const HitRec& h,
                                        ShadeOut& o, Counters& cnt, TravStack& st) {
   if (STATS) cnt.shade_calls++;
@@ -1052,13 +1135,13 @@ __device__ inline void shade_hit_local(const DScene& S, const Ray& ray, const Hi
     double distance;
     shadow_ray(L, pr.over, sr, distance);
     if (STATS) cnt.rays_shadow++;
-    bool shadow = trace_any<STATS>(S, sr, distance, cnt, st);
+    bool shadow = trace_any<STATS, FAST>(S, sr, distance, cnt, st);
     // lightv = normalize(light.position - position) is the shadow ray's direction
     add_light(M, L, pc, sr.d, pr.normal, eyev, shadow, surface);
   }
   o.surface = surface;
   double n1 = 1.0, n2 = 1.0;
-  if (needs_n1_n2(M)) containers_n1_n2<STATS>(S, ray, h, M.refractive_index, n1, n2, cnt, st);
+  if (needs_n1_n2(M)) containers_n1_n2<STATS, FAST>(S, ray, h, M.refractive_index, n1, n2, cnt, st);
   finish_optics(M, ray, pr, n1, n2, o);
 }
 

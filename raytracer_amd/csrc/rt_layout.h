@@ -38,6 +38,11 @@ struct alignas(16) DTri {
   uint32_t orig;    // index in face order (for the leaf order and tie-breaks)
   uint32_t smooth;  // 1: interpolate vertex normals, 0: flat normal
 };
+// The same triangle in f32 for the fast arithmetic mode.  48 bytes.
+struct alignas(16) DTriF {
+  float p1[3], e1[3], e2[3];
+  uint32_t orig, smooth, pad;
+};
 // Normals, fetched only for the final hit: n1,n2,n3 (smooth) or the flat normal in n[0..2].
 struct alignas(8) DTriN {
   double n[9];
@@ -73,6 +78,7 @@ struct DScene {
   const DPrimBox* prim_boxes;
   const DMesh* meshes;
   const DTri* tris;
+  const DTriF* trisf;  // same order as tris
   const DTriN* trin;
   const DNode* nodes;
   const DMaterial* mats;
