@@ -552,6 +552,7 @@ __device__ __forceinline__ bool key_less(const Key& a, const Key& b) {
 
 enum { Q_CLOSEST = 0, Q_ANY = 1, Q_PRED = 2 };
 
+
 // State of one query over the meshes.
 //   Q_CLOSEST: smallest t > 0, ties by leaf order  (hi = best t so far)
 //   Q_ANY:     is there 0 < t < hi
@@ -662,14 +663,15 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
       qlo = f32_down(0.0 - c.t_base);
       qhi = (q.hi < 1e300) ? f32_up(q.hi - c.t_base) : __builtin_huge_valf();
     }
-    // "while-while" traversal: every lane first descends inner nodes until it holds a leaf
-    // (or runs out), then the lanes test their leaves' triangles together, so that node
-    // fetches and triangle tests each run with as many active lanes as possible.  Stack and
-    // `cur` hold inner node indices (>= 0) or leaf codes (<= -2); -1 means nothing left.
+    // "while-while" traversal: the lanes descend inner nodes together, then test the
+    // triangles of the leaves they hold together, so that node fetches and triangle tests
+    // each run with as many active lanes as possible.  Stack and `cur` hold inner node
+    // indices (>= 0) or leaf codes (<= -2); -1 means nothing left.
     int sp = 0;
     int cur = M.root;
     unsigned long long visited = 0;
     while (cur != -1) {
+      const int alive = __popcll(__ballot(true));  // lanes of this wave still walking this mesh
       while (cur >= 0) {
         const NodeR N = load_node(S.nodes + cur);
         if (STATS) {
@@ -697,8 +699,13 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
         } else {
           cur = sp ? st.get(--sp) : -1;
         }
+        // Once fewer than half of the wave's walking lanes are still descending, the rest
+        // wait with a leaf: test those now and let the stragglers descend on their next turn.
+        // Measured on MI355X (pawn 1080p): waiting for every lane 8.5 ms, this rule 7.05 ms;
+        // thresholds of 1/8, 1/4, 3/4 and "any lane has a leaf" were all slower.
+        if (__popcll(__ballot(cur >= 0)) * 2 < alive) break;
       }
-      if (cur != -1) {
+      if (cur <= -2) {
         int code = -2 - cur;
         const bool done = FAST ? test_leaf<MODE, STATS>(order_base, tri_base, m, trisf, code >> 3, code & 7, lr, lrf, q, cnt)
                                : test_leaf<MODE, STATS>(order_base, tri_base, m, tris, code >> 3, code & 7, lr, lrf, q, cnt);
