@@ -198,6 +198,37 @@ void set_empty(rtd::DNode& N, int which) {
 
 }  // namespace
 
+void reorder_top_breadth_first(std::vector<rtd::DNode>& nodes, int top) {
+  const int n = (int)nodes.size();
+  if (n <= 2 || top <= 1) return;
+  std::vector<int> order;  // new position -> old index
+  order.reserve(n);
+  std::vector<char> taken(n, 0);
+  order.push_back(0);
+  taken[0] = 1;
+  for (size_t head = 0; head < order.size() && (int)order.size() < top; head++) {
+    const rtd::DNode& N = nodes[order[head]];
+    const int cs[2] = {N.c0, N.c1};
+    for (int c : cs)
+      if (c >= 0 && c < n && !taken[c] && (int)order.size() < top) {
+        order.push_back(c);
+        taken[c] = 1;
+      }
+  }
+  for (int i = 0; i < n; i++)
+    if (!taken[i]) order.push_back(i);
+  std::vector<int> where(n);
+  for (int k = 0; k < n; k++) where[order[k]] = k;
+  std::vector<rtd::DNode> out(n);
+  for (int k = 0; k < n; k++) {
+    rtd::DNode N = nodes[order[k]];
+    if (N.c0 >= 0) N.c0 = where[N.c0];
+    if (N.c1 >= 0) N.c1 = where[N.c1];
+    out[k] = N;
+  }
+  nodes.swap(out);
+}
+
 void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, int max_leaf,
                BuildResult& out) {
   out.nodes.clear();

@@ -30,6 +30,11 @@ void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, 
 int build_lbvh_device(const double* p1, const double* p2, const double* p3, int64_t n, int max_leaf,
                       BuildResult& out, std::string& err);
 
+// Moves the top of the tree to the front of `nodes`: the first `top` entries become the
+// nodes nearest the root in breadth-first order (the root stays entry 0); the others keep
+// their relative order.  Kernels stage those first entries in LDS.
+void reorder_top_breadth_first(std::vector<rtd::DNode>& nodes, int top);
+
 // Relative padding applied to every box, times the largest |coordinate| of the mesh.
 constexpr double BOX_PAD_REL = 1e-7;
 

@@ -221,7 +221,7 @@ template <bool STATS>
 __global__ void __launch_bounds__(64)
 k_render_mega(DScene S, DCamera cam, PixelMap pm, int depth, double* out_f64, uint8_t* out_u8,
               unsigned long long* counters) {
-  RT_TRAV_STACK(st);
+  RT_TRAV_STACK(st, S);
   Counters cnt{};
   int px, py;
   long long oi;
@@ -246,8 +246,8 @@ k_render_mega(DScene S, DCamera cam, PixelMap pm, int depth, double* out_f64, ui
 __global__ void __launch_bounds__(64) k_trace_rays(DScene S, long long n, const double* origins, const double* dirs,
                              int depth, double* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  RT_TRAV_STACK(st, S);
   if (i >= n) return;
-  RT_TRAV_STACK(st);
   Counters cnt{};
   Ray r = {v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
            v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2])};
@@ -334,7 +334,7 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
            unsigned int cap, WfNode* nodes, WfTask* next, unsigned int* next_count,
            unsigned int next_cap, int spawn, unsigned long long* counters) {
   static_assert(WF_BLOCK == 64, "the traversal stack is laid out for 64-lane blocks");
-  RT_TRAV_STACK(st);
+  RT_TRAV_STACK(st, S);
   Counters cnt{};
   long long i = (long long)blockIdx.x * WF_BLOCK + threadIdx.x;
   bool active;
@@ -696,6 +696,7 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     }
     if (br.max_depth >= STACK_MAX - 2)
       return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+    rtb::reorder_top_breadth_first(br.nodes, TOP_NODES);
     DMesh& M = meshes[mi];
     M.group = h.group;
     M.material = h.material;
@@ -703,6 +704,8 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     M.root = (int32_t)nodes.size();
     M.tri_base = (int32_t)tris.size();
     M.ntris = (int32_t)h.ntris;
+    M.n_nodes = (int32_t)br.nodes.size();
+    M.pad = 0;
     for (int a = 0; a < 3; a++) {
       M.lo[a] = br.lo[a];
       M.hi[a] = br.hi[a];

@@ -353,14 +353,17 @@ struct NodeR {
   uint32_t q[6];
   int32_t c0, c1;
 };
-__device__ __forceinline__ NodeR load_node(const DNode* p) {
-  const uint4* w = reinterpret_cast<const uint4*>(p);
-  uint4 a = w[0], b = w[1];
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ NodeR node_from(u32x4 a, u32x4 b) {
   NodeR r;
   r.q[0] = a.x; r.q[1] = a.y; r.q[2] = a.z; r.q[3] = a.w;
   r.q[4] = b.x; r.q[5] = b.y;
   r.c0 = (int32_t)b.z; r.c1 = (int32_t)b.w;
   return r;
+}
+__device__ __forceinline__ NodeR load_node(const DNode* p) {
+  const u32x4* w = reinterpret_cast<const u32x4*>(p);
+  return node_from(w[0], w[1]);
 }
 // One triangle record as five 16-byte loads.  pin() makes the values live at one point, so
 // the compiler issues all the loads of a batch back to back and waits once, instead of
@@ -514,10 +517,23 @@ struct HitRec {
 // The LDS pointer carries its address space so pushes and pops are plain ds_write/ds_read.
 constexpr int STACK_MAX = 64;
 constexpr int LDS_STACK = 24;
+// Build option RT_STAGE_TOP=1: the top of every mesh's tree (the builders put it first,
+// breadth first) is staged in LDS once per block, TOP_NODES 32-byte nodes shared evenly by
+// the scene's meshes (none when there are more than TOP_NODES / 8 meshes).  Off by default:
+// measured on MI355X it costs 6 % on the pawn frame and 20 % on the 1M-triangle scene — the
+// top of the tree is L1-resident anyway, and the extra branch splits the node fetch into an
+// LDS group and a global group of lanes.
+#ifndef RT_STAGE_TOP
+#define RT_STAGE_TOP 0
+#endif
+constexpr int TOP_NODES = 128;
 typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 struct TravStack {
-  lds_int* lds;  // this lane's column
-  int* spill;    // STACK_MAX - LDS_STACK private words
+  lds_int* lds;     // this lane's column
+  int* spill;       // STACK_MAX - LDS_STACK private words
+  lds_u32x4* top;   // staged nodes: mesh m's node k at top[2 * (m * top_per_mesh + k)]
+  int top_per_mesh;
   __device__ __forceinline__ void put(int i, int v) {
     if (i < LDS_STACK)
       lds[i * 64] = v;
@@ -529,12 +545,27 @@ struct TravStack {
   }
 };
 // In a kernel of 64-thread blocks: RT_TRAV_STACK(st) declares the storage and the handle.
-#define RT_TRAV_STACK(name)                                                     \
+__device__ __forceinline__ int stage_top_nodes(const DScene& S, lds_u32x4* top) {
+  if (!RT_STAGE_TOP) return 0;
+  int per = (S.n_meshes > 0 && S.n_meshes <= TOP_NODES / 8) ? TOP_NODES / S.n_meshes : 0;
+  const u32x4* src = reinterpret_cast<const u32x4*>(S.nodes);
+  for (int j = threadIdx.x; j < 2 * per * S.n_meshes; j += 64) {
+    int slot = j >> 1, m = slot / per, k = slot - m * per;
+    const DMesh& M = S.meshes[m];
+    if (k < M.n_nodes) top[j] = src[2 * (size_t)(M.root + k) + (j & 1)];
+  }
+  __syncthreads();
+  return per;
+}
+#define RT_TRAV_STACK(name, scene)                                              \
   __shared__ int name##_lds[rtd::LDS_STACK * 64];                               \
+  __shared__ rtd::u32x4 name##_top[2 * rtd::TOP_NODES];                         \
   int name##_spill[rtd::STACK_MAX - rtd::LDS_STACK];                            \
   rtd::TravStack name;                                                          \
   name.lds = (rtd::lds_int*)(name##_lds) + threadIdx.x;                         \
-  name.spill = name##_spill
+  name.spill = name##_spill;                                                    \
+  name.top = (rtd::lds_u32x4*)(name##_top);                                     \
+  name.top_per_mesh = rtd::stage_top_nodes(scene, name.top)
 
 // Sort key of one entry of the reference's intersection list: ascending t, ties by leaf
 // order, then by emission order inside one shape (stable sorts, group.rs:69, world.rs:29).
@@ -673,7 +704,16 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
     while (cur != -1) {
       const int alive = __popcll(__ballot(true));  // lanes of this wave still walking this mesh
       while (cur >= 0) {
-        const NodeR N = load_node(S.nodes + cur);
+        NodeR N;
+        {
+          const int k = cur - M.root;
+          if (RT_STAGE_TOP && k < st.top_per_mesh) {
+            const lds_u32x4* w = st.top + 2 * (m * st.top_per_mesh + k);
+            N = node_from(w[0], w[1]);
+          } else {
+            N = load_node(S.nodes + cur);
+          }
+        }
         if (STATS) {
           if (wave_leader()) cnt.node_wave_steps++;
           cnt.nodes_visited++;

@@ -30,6 +30,8 @@ struct alignas(16) DMesh {
   int32_t root;         // index of the root node in the node table
   int32_t tri_base;     // first record in the triangle table
   int32_t ntris;
+  int32_t n_nodes;      // nodes of this mesh; the first ones are the top of the tree, breadth first
+  int32_t pad;
 };
 // One triangle as the intersection test reads it: p1, e1 = p2-p1, e2 = p3-p1
 // (triangle.rs:49-50).  80 bytes.
