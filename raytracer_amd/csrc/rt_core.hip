@@ -71,6 +71,11 @@ struct rt_scene {
   unsigned int* wf_counts_host = nullptr;  // pinned
   // queue lengths of the last frame rendered with host read-backs: the same frame (camera,
   // shard, depth, mode) is then issued again without any synchronisation
+  // Wavefront kernels share the triangle tests of a wave's leaves between all its lanes
+  // (traverse_meshes_coop).  That pays when neighbouring rays are incoherent — scenes with
+  // refraction: pawn 1080p 7.0 -> 6.3 ms — and costs otherwise (tea set 1.07 -> 1.3 ms), so
+  // it is switched on by the presence of a transparent material.  RT_SHARE_LEAVES=0/1 overrides.
+  bool share_leaves = false;
   uint64_t wf_plan_key = 0;
   int wf_plan_levels = 0;
   long long wf_plan_n[MAX_DEPTH + 1] = {}, wf_plan_front[MAX_DEPTH + 1] = {};
@@ -328,17 +333,72 @@ constexpr int WF_BLOCK = 64;
 #ifndef WF_WAVES
 #define WF_WAVES 4
 #endif
-template <bool STATS, bool PRIMARY, bool FAST>
+// Fills the level's result node and appends the child rays to the next level's queue:
+// reflected rays from the front, refracted rays from the back (world.rs:78-114).
+template <bool STATS>
+__device__ __forceinline__ void emit_result(const ShadeOut& so, const C3& surface, WfNode& nd, long long i,
+                                            WfTask* next, unsigned int* next_count, unsigned int next_cap,
+                                            int spawn, Counters& cnt) {
+  nd.surface[0] = surface.r;
+  nd.surface[1] = surface.g;
+  nd.surface[2] = surface.b;
+  nd.reflectance = so.reflectance;
+  nd.flags |= 1u | (so.use_schlick ? 2u : 0u);
+  for (int k = 0; k < 3; k++) {
+    nd.reflected[k] = 0.0;
+    nd.refracted[k] = 0.0;
+  }
+  if (so.do_reflect) {
+    if (spawn) {
+      unsigned int idx = atomicAdd(next_count, 1u);
+      if (idx < next_cap) {
+        WfTask& T = next[idx];
+        T.o[0] = so.reflect_ray.o.x;
+        T.o[1] = so.reflect_ray.o.y;
+        T.o[2] = so.reflect_ray.o.z;
+        T.d[0] = so.reflect_ray.d.x;
+        T.d[1] = so.reflect_ray.d.y;
+        T.d[2] = so.reflect_ray.d.z;
+        T.coef = so.reflective;
+        T.parent = (int32_t)i;
+        T.slot = 0;
+      }
+    } else if (STATS) {
+      cnt.depth0_skipped++;
+    }
+  }
+  if (so.do_refract) {
+    if (spawn) {
+      unsigned int idx = atomicAdd(next_count + 1, 1u);
+      if (idx < next_cap) {
+        WfTask& T = next[next_cap - 1 - idx];
+        T.o[0] = so.refract_ray.o.x;
+        T.o[1] = so.refract_ray.o.y;
+        T.o[2] = so.refract_ray.o.z;
+        T.d[0] = so.refract_ray.d.x;
+        T.d[1] = so.refract_ray.d.y;
+        T.d[2] = so.refract_ray.d.z;
+        T.coef = so.transparency;
+        T.parent = (int32_t)i;
+        T.slot = 1;
+      }
+    } else if (STATS) {
+      cnt.depth0_skipped++;
+    }
+  }
+}
+
+template <bool STATS, bool PRIMARY, bool FAST, bool COOP>
 __global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
 k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n, long long n_front,
            unsigned int cap, WfNode* nodes, WfTask* next, unsigned int* next_count,
            unsigned int next_cap, int spawn, unsigned long long* counters) {
   static_assert(WF_BLOCK == 64, "the traversal stack is laid out for 64-lane blocks");
-  RT_TRAV_STACK(st, S);
+  RT_TRAV_STACK_COOP(st, S);
   Counters cnt{};
   long long i = (long long)blockIdx.x * WF_BLOCK + threadIdx.x;
   bool active;
-  Ray ray;
+  Ray ray = {v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 1.0)};
   WfNode nd;
   nd.flags = 0;
   nd.coef = 0.0;
@@ -369,57 +429,56 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
       }
     }
   }
-  if (active) {
+  if (COOP) {
+    // Every lane of the wave goes through the three queries together (the lanes share the
+    // triangle tests of each other's leaves); `active`, `hit` and `need` say who has one.
     HitRec h;
-    if (trace_closest<STATS, FAST>(S, ray, h, cnt, st)) {
+    const bool hit = trace_closest_coop<STATS, FAST>(S, ray, active, h, cnt, st);
+    Prep pr;
+    pr.mat_index = 0;
+    C3 surface = {0.0, 0.0, 0.0};
+    C3 pc = {0.0, 0.0, 0.0};
+    if (hit) {
+      if (STATS) cnt.shade_calls++;
+      pr = prepare_hit(S, ray, h);
+      pc = hit_pattern_color(S, S.mats[pr.mat_index], pr);
+    }
+    for (int li = 0; li < S.n_lights; li++) {
+      const DLight& L = S.lights[li];
+      Ray sr = ray;
+      double distance = 0.0;
+      if (hit) {
+        shadow_ray(L, pr.over, sr, distance);
+        if (STATS) cnt.rays_shadow++;
+      }
+      const bool shadow = trace_any_coop<STATS, FAST>(S, sr, distance, hit, cnt, st);
+      if (hit) add_light(S.mats[pr.mat_index], L, pc, sr.d, pr.normal, vneg(ray.d), shadow, surface);
+    }
+    const bool need = hit && needs_n1_n2(S.mats[pr.mat_index]);
+    Key K{0.0, 0u, 0}, tb{0.0, 0u, 0};
+    int tm = -1;
+    if (need) {
+      if (STATS) cnt.pred_queries++;
+      K = trigger_key(S, ray, h);
+    }
+    bool tf = false;
+    if (S.n_meshes > 0)
+      tf = tri_predecessor_coop<STATS, FAST>(S, ray, K, h.prim >= 0 ? -1 : h.tri, need, tb, tm, cnt, st);
+    if (hit) {
+      const DMaterial& M = S.mats[pr.mat_index];
+      double n1 = 1.0, n2 = 1.0;
+      if (need) containers_from<STATS>(S, ray, h, K, M.refractive_index, tf, tb, tm, n1, n2, cnt);
       ShadeOut so;
-      shade_hit_local<STATS, FAST>(S, ray, h, so, cnt, st);
-      nd.surface[0] = so.surface.r;
-      nd.surface[1] = so.surface.g;
-      nd.surface[2] = so.surface.b;
-      nd.reflectance = so.reflectance;
-      nd.flags |= 1u | (so.use_schlick ? 2u : 0u);
-      for (int k = 0; k < 3; k++) {
-        nd.reflected[k] = 0.0;
-        nd.refracted[k] = 0.0;
-      }
-      if (so.do_reflect) {
-        if (spawn) {
-          unsigned int idx = atomicAdd(next_count, 1u);
-          if (idx < next_cap) {
-            WfTask& T = next[idx];
-            T.o[0] = so.reflect_ray.o.x;
-            T.o[1] = so.reflect_ray.o.y;
-            T.o[2] = so.reflect_ray.o.z;
-            T.d[0] = so.reflect_ray.d.x;
-            T.d[1] = so.reflect_ray.d.y;
-            T.d[2] = so.reflect_ray.d.z;
-            T.coef = so.reflective;
-            T.parent = (int32_t)i;
-            T.slot = 0;
-          }
-        } else if (STATS) {
-          cnt.depth0_skipped++;
-        }
-      }
-      if (so.do_refract) {
-        if (spawn) {
-          unsigned int idx = atomicAdd(next_count + 1, 1u);
-          if (idx < next_cap) {
-            WfTask& T = next[next_cap - 1 - idx];
-            T.o[0] = so.refract_ray.o.x;
-            T.o[1] = so.refract_ray.o.y;
-            T.o[2] = so.refract_ray.o.z;
-            T.d[0] = so.refract_ray.d.x;
-            T.d[1] = so.refract_ray.d.y;
-            T.d[2] = so.refract_ray.d.z;
-            T.coef = so.transparency;
-            T.parent = (int32_t)i;
-            T.slot = 1;
-          }
-        } else if (STATS) {
-          cnt.depth0_skipped++;
-        }
+      finish_optics(M, ray, pr, n1, n2, so);
+      emit_result<STATS>(so, surface, nd, i, next, next_count, next_cap, spawn, cnt);
+    }
+  } else {
+    if (active) {
+      HitRec h;
+      if (trace_closest<STATS, FAST>(S, ray, h, cnt, st)) {
+        ShadeOut so;
+        shade_hit_local<STATS, FAST>(S, ray, h, so, cnt, st);
+        emit_result<STATS>(so, so.surface, nd, i, next, next_count, next_cap, spawn, cnt);
       }
     }
   }
@@ -776,6 +835,10 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   if ((rc = upload(s, nodes, &s->d.nodes))) return rc;
   if ((rc = upload(s, mats, &s->d.mats))) return rc;
   if ((rc = upload(s, s->lights, &s->d.lights))) return rc;
+  s->share_leaves = false;
+  for (const rt_material& m : s->mats)
+    if (m.transparency != 0.0) s->share_leaves = true;
+  if (const char* e = getenv("RT_SHARE_LEAVES")) s->share_leaves = atoi(e) != 0;
   s->d.n_groups = (int32_t)groups.size();
   s->d.n_prims = (int32_t)prims.size();
   s->d.n_meshes = (int32_t)meshes.size();
@@ -893,15 +956,19 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     WfTask* tnext = spawn ? static_cast<WfTask*>(s->wf_tasks[l + 1]) : nullptr;
     unsigned int cap = spawn ? (unsigned int)std::min<size_t>(s->wf_task_cap[l + 1], 0xffffffffu) : 0u;
     unsigned int* cnt_next = s->wf_counts + 2 * (l + 1);
-#define WF_LAUNCH(ST, PR, FA)                                                                        \
-  hipLaunchKernelGGL((k_wf_level<ST, PR, FA>), grid, block, 0, st, s->d, dc, pm, tin, n, n_front, cap_in, \
+#define WF_LAUNCH(ST, PR, FA, CO)                                                                        \
+  hipLaunchKernelGGL((k_wf_level<ST, PR, FA, CO>), grid, block, 0, st, s->d, dc, pm, tin, n, n_front, cap_in, \
                      nodes, tnext, cnt_next, cap, spawn ? 1 : 0, s->d_counters)
-#define WF_LAUNCH2(ST, PR) \
-  do {                     \
-    if (fast)              \
-      WF_LAUNCH(ST, PR, true); \
-    else                   \
-      WF_LAUNCH(ST, PR, false); \
+#define WF_LAUNCH2(ST, PR)              \
+  do {                                  \
+    if (fast && s->share_leaves)        \
+      WF_LAUNCH(ST, PR, true, true);    \
+    else if (fast)                      \
+      WF_LAUNCH(ST, PR, true, false);   \
+    else if (s->share_leaves)           \
+      WF_LAUNCH(ST, PR, false, true);   \
+    else                                \
+      WF_LAUNCH(ST, PR, false, false);  \
   } while (0)
     if (l == 0) {
       if (stats) WF_LAUNCH2(true, true); else WF_LAUNCH2(false, true);

@@ -527,6 +527,7 @@ constexpr int LDS_STACK = 24;
 #define RT_STAGE_TOP 0
 #endif
 constexpr int TOP_NODES = 128;
+constexpr int COOP_SLOTS = 64 * 7;  // a leaf holds at most 7 triangles
 typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 struct TravStack {
@@ -534,6 +535,8 @@ struct TravStack {
   int* spill;       // STACK_MAX - LDS_STACK private words
   lds_u32x4* top;   // staged nodes: mesh m's node k at top[2 * (m * top_per_mesh + k)]
   int top_per_mesh;
+  lds_u32x4* rays;                                          // cooperative leaf tests: lane l's ray at rays[3*l..]
+  __attribute__((address_space(3))) unsigned char* owners;  // ... and the slot -> lane table
   __device__ __forceinline__ void put(int i, int v) {
     if (i < LDS_STACK)
       lds[i * 64] = v;
@@ -559,13 +562,22 @@ __device__ __forceinline__ int stage_top_nodes(const DScene& S, lds_u32x4* top) 
 }
 #define RT_TRAV_STACK(name, scene)                                              \
   __shared__ int name##_lds[rtd::LDS_STACK * 64];                               \
-  __shared__ rtd::u32x4 name##_top[2 * rtd::TOP_NODES];                         \
+  __shared__ rtd::u32x4 name##_top[RT_STAGE_TOP ? 2 * rtd::TOP_NODES : 1];      \
   int name##_spill[rtd::STACK_MAX - rtd::LDS_STACK];                            \
   rtd::TravStack name;                                                          \
   name.lds = (rtd::lds_int*)(name##_lds) + threadIdx.x;                         \
   name.spill = name##_spill;                                                    \
   name.top = (rtd::lds_u32x4*)(name##_top);                                     \
-  name.top_per_mesh = rtd::stage_top_nodes(scene, name.top)
+  name.top_per_mesh = rtd::stage_top_nodes(scene, name.top);                    \
+  name.rays = nullptr;                                                          \
+  name.owners = nullptr
+// ... plus the areas the cooperative leaf test shares between the lanes of the wave.
+#define RT_TRAV_STACK_COOP(name, scene)                                         \
+  RT_TRAV_STACK(name, scene);                                                   \
+  __shared__ rtd::u32x4 name##_rays[3 * 64];                                    \
+  __shared__ unsigned char name##_owners[rtd::COOP_SLOTS];                      \
+  name.rays = (rtd::lds_u32x4*)(name##_rays);                                   \
+  name.owners = (__attribute__((address_space(3))) unsigned char*)(name##_owners)
 
 // Sort key of one entry of the reference's intersection list: ascending t, ties by leaf
 // order, then by emission order inside one shape (stable sorts, group.rs:69, world.rs:29).
@@ -763,6 +775,188 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
   return false;
 }
 
+// ---------------------------------------------------------------------------------------
+// Cooperative traversal: the same walk as traverse_meshes, called by ALL 64 lanes of a wave
+// in uniform control flow (`enabled` says whether this lane has a query).  Inner nodes are
+// walked per lane as before.  The leaf phase is shared: the (lane, triangle) pairs of every
+// leaf held in the wave are dealt out over all 64 lanes, so a phase in which 10 lanes hold
+// leaves of 1-6 triangles costs one 64-wide test instead of three 10-wide pair tests.  A
+// worker only reports "this triangle is a candidate"; the owner evaluates its candidates
+// itself with the ordinary test, so the accepted values are those of the per-lane path.
+template <int MODE, bool STATS, bool FAST>
+__device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Query& q, bool enabled,
+                                            Counters& cnt, TravStack& st) {
+  const int lane = threadIdx.x & 63;
+  bool satisfied = false;  // Q_ANY: this lane has its answer
+  for (int m = 0; m < S.n_meshes; m++) {
+    const DMesh& M = S.meshes[m];
+    Ray lr = ray;
+    CullRay c;
+    c.miss = true;
+    c.t_base = 0.0;
+    for (int a = 0; a < 3; a++) {
+      c.a[a] = 0.f; c.cn[a] = 0.f; c.cf[a] = 0.f; c.sh[a] = 0;
+    }
+    const bool walking0 = enabled && !satisfied;
+    if (walking0) {
+      lr = ray_to_group(S, M.group, ray);
+      if (STATS) cnt.inst_entries++;
+      c = make_cull_ray(M, lr, MODE == Q_PRED);
+    }
+    const int tri_base = M.tri_base;
+    const uint32_t order_base = M.order_base;
+    const DTri* tris = S.tris + tri_base;
+    const DTriF* trisf = S.trisf + tri_base;
+    const RayF lrf = {(float)lr.o.x, (float)lr.o.y, (float)lr.o.z, (float)lr.d.x, (float)lr.d.y, (float)lr.d.z};
+    // every lane publishes its object-space ray for the workers
+    {
+      u32x4 w0, w1, w2;
+      w0.x = (unsigned)__double2loint(lr.o.x); w0.y = (unsigned)__double2hiint(lr.o.x);
+      w0.z = (unsigned)__double2loint(lr.o.y); w0.w = (unsigned)__double2hiint(lr.o.y);
+      w1.x = (unsigned)__double2loint(lr.o.z); w1.y = (unsigned)__double2hiint(lr.o.z);
+      w1.z = (unsigned)__double2loint(lr.d.x); w1.w = (unsigned)__double2hiint(lr.d.x);
+      w2.x = (unsigned)__double2loint(lr.d.y); w2.y = (unsigned)__double2hiint(lr.d.y);
+      w2.z = (unsigned)__double2loint(lr.d.z); w2.w = (unsigned)__double2hiint(lr.d.z);
+      st.rays[3 * lane + 0] = w0;
+      st.rays[3 * lane + 1] = w1;
+      st.rays[3 * lane + 2] = w2;
+    }
+    float qlo = 0.f, qhi = 0.f;
+    if (MODE == Q_PRED) {
+      qlo = q.found ? f32_down(q.best.t - c.t_base) : -__builtin_huge_valf();
+      qhi = f32_up(q.hi - c.t_base);
+    } else {
+      qlo = f32_down(0.0 - c.t_base);
+      qhi = (q.hi < 1e300) ? f32_up(q.hi - c.t_base) : __builtin_huge_valf();
+    }
+    int sp = 0;
+    int cur = (walking0 && !c.miss) ? M.root : -1;
+    unsigned long long visited = 0;
+    while (__ballot(cur != -1) != 0ull) {  // wave-uniform
+      const int alive = __popcll(__ballot(cur != -1));
+      while (cur >= 0) {
+        const NodeR N = load_node(S.nodes + cur);
+        if (STATS) {
+          if (wave_leader()) cnt.node_wave_steps++;
+          cnt.nodes_visited++;
+          visited++;
+          if (visited > cnt.max_nodes) cnt.max_nodes = visited;
+        }
+        float tn0, tf0, tn1, tf1;
+        slab32(N.q, c, tn0, tf0);
+        slab32(N.q + 3, c, tn1, tf1);
+        bool h0 = fmaxf(tn0, qlo) <= fminf(tf0, qhi) && N.c0 != -1;
+        bool h1 = fmaxf(tn1, qlo) <= fminf(tf1, qhi) && N.c1 != -1;
+        if (h0 && h1) {
+          bool second_first = (MODE == Q_PRED) ? (tf1 > tf0) : (tn1 < tn0);
+          int near = second_first ? N.c1 : N.c0;
+          int far = second_first ? N.c0 : N.c1;
+          if (sp < STACK_MAX) st.put(sp++, far);
+          cur = near;
+        } else if (h0) {
+          cur = N.c0;
+        } else if (h1) {
+          cur = N.c1;
+        } else {
+          cur = sp ? st.get(--sp) : -1;
+        }
+        if (__popcll(__ballot(cur >= 0)) * 2 < alive) break;
+      }
+      // ---- shared leaf phase (all 64 lanes)
+      const bool has_leaf = cur <= -2;
+      const int code = has_leaf ? -2 - cur : 0;
+      const int lfirst = code >> 3;
+      const int lcount = has_leaf ? (code & 7) : 0;
+      // prefix sum of the counts (3-bit numbers) from three ballots: no cross-lane data movement
+      const unsigned long long b0 = __ballot(lcount & 1), b1 = __ballot(lcount & 2), b2 = __ballot(lcount & 4);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const int off = __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
+      const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+      unsigned candidates = 0;  // bit j: triangle lfirst + j of my leaf passed a worker's test
+      {
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+          if (j < lcount) st.owners[off + j] = (unsigned char)lane;
+        for (int base = 0; base < total; base += 64) {  // wave-uniform
+          const int s = base + lane;
+          const bool work = s < total;
+          const int o = work ? (int)st.owners[s] : lane;
+          const int o_off = __shfl(off, o, 64);
+          const int o_first = __shfl(lfirst, o, 64);
+          bool ok = false;
+          if (work) {
+            const int rec = o_first + (s - o_off);
+            if (STATS) {
+              if (wave_leader()) cnt.tri_wave_steps++;
+              cnt.tri_tests++;
+            }
+            const u32x4 w0 = st.rays[3 * o + 0], w1 = st.rays[3 * o + 1], w2 = st.rays[3 * o + 2];
+            if (FAST) {
+              RayF rf;
+              rf.ox = (float)__hiloint2double((int)w0.y, (int)w0.x);
+              rf.oy = (float)__hiloint2double((int)w0.w, (int)w0.z);
+              rf.oz = (float)__hiloint2double((int)w1.y, (int)w1.x);
+              rf.dx = (float)__hiloint2double((int)w1.w, (int)w1.z);
+              rf.dy = (float)__hiloint2double((int)w2.y, (int)w2.x);
+              rf.dz = (float)__hiloint2double((int)w2.w, (int)w2.z);
+              auto raw = load_tri_raw(trisf + rec);
+              float t, u, v;
+              ok = moller_trumbore_f32(decode_tri(raw), rf, t, u, v) && (MODE == Q_PRED || t > 0.0f);
+            } else {
+              Ray r;
+              r.o = v3(__hiloint2double((int)w0.y, (int)w0.x), __hiloint2double((int)w0.w, (int)w0.z),
+                       __hiloint2double((int)w1.y, (int)w1.x));
+              r.d = v3(__hiloint2double((int)w1.w, (int)w1.z), __hiloint2double((int)w2.y, (int)w2.x),
+                       __hiloint2double((int)w2.w, (int)w2.z));
+              TriRaw raw = load_tri_raw(tris + rec);
+              pin(raw);
+              double t, u, v;
+              ok = moller_trumbore(decode_tri(raw), r, t, u, v) && (MODE == Q_PRED || t > 0.0);
+            }
+          }
+          const unsigned long long mask = __ballot(ok);
+          // my slots inside this chunk
+          const int lo = max(off, base), hi = min(off + lcount, base + 64);
+          if (lo < hi) {
+            unsigned long long bits = (mask >> (lo - base)) & ((1ull << (hi - lo)) - 1ull);
+            candidates |= (unsigned)bits << (lo - off);
+          }
+        }
+      }
+      // ---- owners evaluate their candidates and move on
+      if (has_leaf) {
+        bool hit_any = false;
+        while (candidates) {
+          const int j = __ffs((int)candidates) - 1;
+          candidates &= candidates - 1;
+          const int rec = lfirst + j;
+          Counters unused{};
+          if (FAST) {
+            auto raw = load_tri_raw(trisf + rec);
+            if (test_tri<MODE, false>(decode_tri(raw), order_base, m, tri_base + rec, lr, lrf, q, unused)) hit_any = true;
+          } else {
+            TriRaw raw = load_tri_raw(tris + rec);
+            pin(raw);
+            if (test_tri<MODE, false>(decode_tri(raw), order_base, m, tri_base + rec, lr, lrf, q, unused)) hit_any = true;
+          }
+        }
+        if (MODE == Q_ANY && hit_any) {
+          satisfied = true;
+          cur = -1;
+        } else {
+          if (MODE == Q_CLOSEST) {
+            if (q.hi < 1e300) qhi = f32_up(q.hi - c.t_base);
+          } else if (MODE == Q_PRED) {
+            if (q.found) qlo = f32_down(q.best.t - c.t_base);
+          }
+          cur = sp ? st.get(--sp) : -1;
+        }
+      }
+    }
+  }
+  return satisfied;
+}
+
 // hit() of intersect.rs:125-139 over the list of world.rs:22-32: smallest t > 0, the
 // earliest leaf among equal t.
 template <bool STATS, bool FAST = false>
@@ -862,6 +1056,111 @@ __device__ inline bool tri_predecessor(const DScene& S, const Ray& ray, const Ke
     best_mesh = q.mesh;
   }
   return q.found;
+}
+
+// The three queries on the cooperative walk.  Called by all 64 lanes; `enabled` = this lane
+// has a query.  Closed-form shapes are tested per lane as in the per-lane versions.
+template <bool STATS, bool FAST>
+__device__ inline bool trace_closest_coop(const DScene& S, const Ray& ray, bool enabled, HitRec& h,
+                                          Counters& cnt, TravStack& st) {
+  Query q;
+  q.hi = RT_INF;
+  q.hi_order = 0xffffffffu;
+  q.found = false;
+  q.mesh = -1;
+  q.tri = -1;
+  q.u = 0.0;
+  q.v = 0.0;
+  q.best = Key{0.0, 0u, 0};
+  int prim = -1;
+  if (enabled) {
+    const BoxRay br = make_box_ray(ray);
+    for (int p = 0; p < S.n_prims; p++) {
+      if (!box_may_hit(S.prim_boxes[p], br, 0.0, q.hi)) continue;
+      const DPrim& P = S.prims[p];
+      Ray lr = ray_to_prim(S, P, ray);
+      double ts[4];
+      int n = prim_local_intersect(P, lr, ts);
+      if (STATS) cnt.prim_tests++;
+      for (int k = 0; k < n; k++) {
+        double t = ts[k];
+        if (t > 0.0 && (t < q.hi || (t == q.hi && P.order < q.hi_order))) {
+          q.hi = t;
+          q.hi_order = P.order;
+          prim = p;
+          q.found = true;
+        }
+      }
+    }
+  }
+  traverse_meshes_coop<Q_CLOSEST, STATS, FAST>(S, ray, q, enabled, cnt, st);
+  if (FAST && enabled && q.mesh >= 0) {
+    const DMesh& M = S.meshes[q.mesh];
+    Ray lr = ray_to_group(S, M.group, ray);
+    double t, u, v;
+    if (moller_trumbore(S.tris[q.tri], lr, t, u, v) && t > 0.0) {
+      q.hi = t;
+      q.u = u;
+      q.v = v;
+    }
+  }
+  h.t = q.hi;
+  h.order = q.hi_order;
+  h.u = q.u;
+  h.v = q.v;
+  h.mesh = q.mesh;
+  h.tri = q.tri;
+  h.prim = (q.mesh >= 0) ? -1 : prim;
+  return enabled && q.found;
+}
+
+template <bool STATS, bool FAST>
+__device__ inline bool trace_any_coop(const DScene& S, const Ray& ray, double distance, bool enabled,
+                                      Counters& cnt, TravStack& st) {
+  bool found = false;
+  if (enabled) {
+    const BoxRay br = make_box_ray(ray);
+    for (int p = 0; p < S.n_prims && !found; p++) {
+      if (!box_may_hit(S.prim_boxes[p], br, 0.0, distance)) continue;
+      const DPrim& P = S.prims[p];
+      Ray lr = ray_to_prim(S, P, ray);
+      double ts[4];
+      int n = prim_local_intersect(P, lr, ts);
+      if (STATS) cnt.prim_tests++;
+      for (int k = 0; k < n; k++)
+        if (ts[k] > 0.0 && ts[k] < distance) found = true;
+    }
+  }
+  Query q;
+  q.hi = distance;
+  q.hi_order = 0;
+  q.found = false;
+  q.mesh = -1;
+  q.tri = -1;
+  q.u = q.v = 0.0;
+  q.best = Key{0.0, 0u, 0};
+  bool mesh_hit = traverse_meshes_coop<Q_ANY, STATS, FAST>(S, ray, q, enabled && !found, cnt, st);
+  return found || mesh_hit;
+}
+
+template <bool STATS, bool FAST>
+__device__ inline bool tri_predecessor_coop(const DScene& S, const Ray& ray, const Key& K, int own_tri,
+                                            bool enabled, Key& best, int& best_mesh, Counters& cnt,
+                                            TravStack& st) {
+  Query q;
+  q.hi = K.t;
+  q.hi_order = K.order;
+  q.found = false;
+  q.mesh = -1;
+  q.tri = own_tri;
+  q.u = q.v = 0.0;
+  q.best = Key{0.0, 0u, 0};
+  traverse_meshes_coop<Q_PRED, STATS, FAST>(S, ray, q, enabled, cnt, st);
+  if (enabled && q.found) {
+    best = q.best;
+    best_mesh = q.mesh;
+  }
+  return enabled && q.found;
 }
 
 // n1/n2 of prepare_computations (intersect.rs:188-222) without the list.
