@@ -72,10 +72,9 @@ struct rt_scene {
   // queue lengths of the last frame rendered with host read-backs: the same frame (camera,
   // shard, depth, mode) is then issued again without any synchronisation
   // Wavefront kernels share the triangle tests of a wave's leaves between all its lanes
-  // (traverse_meshes_coop).  That pays when neighbouring rays are incoherent — scenes with
-  // refraction: pawn 1080p 7.0 -> 6.3 ms — and costs otherwise (tea set 1.07 -> 1.3 ms), so
-  // it is switched on by the presence of a transparent material.  RT_SHARE_LEAVES=0/1 overrides.
-  bool share_leaves = false;
+  // (traverse_meshes_coop): pawn 1080p 7.0 -> 5.5 ms, tea set 1.08 -> 1.01 ms.
+  // RT_SHARE_LEAVES=0 selects the per-lane leaf tests instead.
+  bool share_leaves = true;
   uint64_t wf_plan_key = 0;
   int wf_plan_levels = 0;
   long long wf_plan_n[MAX_DEPTH + 1] = {}, wf_plan_front[MAX_DEPTH + 1] = {};
@@ -835,9 +834,7 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   if ((rc = upload(s, nodes, &s->d.nodes))) return rc;
   if ((rc = upload(s, mats, &s->d.mats))) return rc;
   if ((rc = upload(s, s->lights, &s->d.lights))) return rc;
-  s->share_leaves = false;
-  for (const rt_material& m : s->mats)
-    if (m.transparency != 0.0) s->share_leaves = true;
+  s->share_leaves = true;
   if (const char* e = getenv("RT_SHARE_LEAVES")) s->share_leaves = atoi(e) != 0;
   s->d.n_groups = (int32_t)groups.size();
   s->d.n_prims = (int32_t)prims.size();

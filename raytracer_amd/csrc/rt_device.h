@@ -780,9 +780,9 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
 // in uniform control flow (`enabled` says whether this lane has a query).  Inner nodes are
 // walked per lane as before.  The leaf phase is shared: the (lane, triangle) pairs of every
 // leaf held in the wave are dealt out over all 64 lanes, so a phase in which 10 lanes hold
-// leaves of 1-6 triangles costs one 64-wide test instead of three 10-wide pair tests.  A
-// worker only reports "this triangle is a candidate"; the owner evaluates its candidates
-// itself with the ordinary test, so the accepted values are those of the per-lane path.
+// leaves of 1-6 triangles costs one 64-wide test instead of three 10-wide pair tests.  The
+// owner of a leaf takes the results (t, u, v) of its triangles from the workers' registers;
+// they are the same arithmetic on the same operands as the per-lane path computes.
 template <int MODE, bool STATS, bool FAST>
 __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Query& q, bool enabled,
                                             Counters& cnt, TravStack& st) {
@@ -807,7 +807,6 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
     const uint32_t order_base = M.order_base;
     const DTri* tris = S.tris + tri_base;
     const DTriF* trisf = S.trisf + tri_base;
-    const RayF lrf = {(float)lr.o.x, (float)lr.o.y, (float)lr.o.z, (float)lr.d.x, (float)lr.d.y, (float)lr.d.z};
     // every lane publishes its object-space ray for the workers
     {
       u32x4 w0, w1, w2;
@@ -872,74 +871,72 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
       const unsigned long long below = (1ull << lane) - 1ull;
       const int off = __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
       const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-      unsigned candidates = 0;  // bit j: triangle lfirst + j of my leaf passed a worker's test
-      {
+      bool hit_any = false;
 #pragma unroll
-        for (int j = 0; j < 7; j++)
-          if (j < lcount) st.owners[off + j] = (unsigned char)lane;
-        for (int base = 0; base < total; base += 64) {  // wave-uniform
-          const int s = base + lane;
-          const bool work = s < total;
-          const int o = work ? (int)st.owners[s] : lane;
-          const int o_off = __shfl(off, o, 64);
-          const int o_first = __shfl(lfirst, o, 64);
-          bool ok = false;
-          if (work) {
-            const int rec = o_first + (s - o_off);
-            if (STATS) {
-              if (wave_leader()) cnt.tri_wave_steps++;
-              cnt.tri_tests++;
-            }
-            const u32x4 w0 = st.rays[3 * o + 0], w1 = st.rays[3 * o + 1], w2 = st.rays[3 * o + 2];
-            if (FAST) {
-              RayF rf;
-              rf.ox = (float)__hiloint2double((int)w0.y, (int)w0.x);
-              rf.oy = (float)__hiloint2double((int)w0.w, (int)w0.z);
-              rf.oz = (float)__hiloint2double((int)w1.y, (int)w1.x);
-              rf.dx = (float)__hiloint2double((int)w1.w, (int)w1.z);
-              rf.dy = (float)__hiloint2double((int)w2.y, (int)w2.x);
-              rf.dz = (float)__hiloint2double((int)w2.w, (int)w2.z);
-              auto raw = load_tri_raw(trisf + rec);
-              float t, u, v;
-              ok = moller_trumbore_f32(decode_tri(raw), rf, t, u, v) && (MODE == Q_PRED || t > 0.0f);
-            } else {
-              Ray r;
-              r.o = v3(__hiloint2double((int)w0.y, (int)w0.x), __hiloint2double((int)w0.w, (int)w0.z),
-                       __hiloint2double((int)w1.y, (int)w1.x));
-              r.d = v3(__hiloint2double((int)w1.w, (int)w1.z), __hiloint2double((int)w2.y, (int)w2.x),
-                       __hiloint2double((int)w2.w, (int)w2.z));
-              TriRaw raw = load_tri_raw(tris + rec);
-              pin(raw);
-              double t, u, v;
-              ok = moller_trumbore(decode_tri(raw), r, t, u, v) && (MODE == Q_PRED || t > 0.0);
-            }
+      for (int j = 0; j < 7; j++)
+        if (j < lcount) st.owners[off + j] = (unsigned char)lane;
+      for (int base = 0; base < total; base += 64) {  // wave-uniform
+        const int s = base + lane;
+        const bool work = s < total;
+        const int o = work ? (int)st.owners[s] : lane;
+        const int o_off = __shfl(off, o, 64);
+        const int o_first = __shfl(lfirst, o, 64);
+        bool ok = false;
+        double wt = 0.0, wu = 0.0, wv = 0.0;  // the worker's result
+        uint32_t worig = 0;
+        if (work) {
+          const int rec = o_first + (s - o_off);
+          if (STATS) {
+            if (wave_leader()) cnt.tri_wave_steps++;
+            cnt.tri_tests++;
           }
-          const unsigned long long mask = __ballot(ok);
-          // my slots inside this chunk
-          const int lo = max(off, base), hi = min(off + lcount, base + 64);
-          if (lo < hi) {
-            unsigned long long bits = (mask >> (lo - base)) & ((1ull << (hi - lo)) - 1ull);
-            candidates |= (unsigned)bits << (lo - off);
+          const u32x4 w0 = st.rays[3 * o + 0], w1 = st.rays[3 * o + 1], w2 = st.rays[3 * o + 2];
+          if (FAST) {
+            RayF rf;
+            rf.ox = (float)__hiloint2double((int)w0.y, (int)w0.x);
+            rf.oy = (float)__hiloint2double((int)w0.w, (int)w0.z);
+            rf.oz = (float)__hiloint2double((int)w1.y, (int)w1.x);
+            rf.dx = (float)__hiloint2double((int)w1.w, (int)w1.z);
+            rf.dy = (float)__hiloint2double((int)w2.y, (int)w2.x);
+            rf.dz = (float)__hiloint2double((int)w2.w, (int)w2.z);
+            const DTriF T = decode_tri(load_tri_raw(trisf + rec));
+            float t, u, v;
+            ok = moller_trumbore_f32(T, rf, t, u, v) && (MODE == Q_PRED || t > 0.0f);
+            wt = (double)t; wu = (double)u; wv = (double)v;
+            worig = T.orig;
+          } else {
+            Ray r;
+            r.o = v3(__hiloint2double((int)w0.y, (int)w0.x), __hiloint2double((int)w0.w, (int)w0.z),
+                     __hiloint2double((int)w1.y, (int)w1.x));
+            r.d = v3(__hiloint2double((int)w1.w, (int)w1.z), __hiloint2double((int)w2.y, (int)w2.x),
+                     __hiloint2double((int)w2.w, (int)w2.z));
+            TriRaw raw = load_tri_raw(tris + rec);
+            pin(raw);
+            const DTri T = decode_tri(raw);
+            ok = moller_trumbore(T, r, wt, wu, wv) && (MODE == Q_PRED || wt > 0.0);
+            worig = T.orig;
+          }
+        }
+        unsigned long long mask = __ballot(ok);
+        // Owners collect the results of their slots in this chunk, one per turn, straight
+        // from the workers' registers: the values are the worker's, i.e. those of the same
+        // arithmetic on the same operands as the per-lane path.
+        const int lo = max(off, base) - base, hi = min(off + lcount, base + 64) - base;  // my slots here
+        unsigned long long mine = (lo < hi) ? (mask >> lo) & ((1ull << (hi - lo)) - 1ull) : 0ull;
+        while (__ballot(mine != 0ull) != 0ull) {  // wave-uniform
+          const int k = mine ? __ffsll((long long)mine) - 1 : 0;
+          const int src = mine ? lo + k : lane;  // worker lane holding my next candidate
+          const double t = __shfl(wt, src, 64), u = __shfl(wu, src, 64), v = __shfl(wv, src, 64);
+          const uint32_t orig = (uint32_t)__shfl((int)worig, src, 64);
+          if (mine) {
+            mine &= mine - 1ull;
+            const int rec = lfirst + (base + lo + k - off);
+            if (accept_hit<MODE>(t, u, v, order_base + orig, m, tri_base + rec, q)) hit_any = true;
           }
         }
       }
-      // ---- owners evaluate their candidates and move on
+      // ---- owners move on
       if (has_leaf) {
-        bool hit_any = false;
-        while (candidates) {
-          const int j = __ffs((int)candidates) - 1;
-          candidates &= candidates - 1;
-          const int rec = lfirst + j;
-          Counters unused{};
-          if (FAST) {
-            auto raw = load_tri_raw(trisf + rec);
-            if (test_tri<MODE, false>(decode_tri(raw), order_base, m, tri_base + rec, lr, lrf, q, unused)) hit_any = true;
-          } else {
-            TriRaw raw = load_tri_raw(tris + rec);
-            pin(raw);
-            if (test_tri<MODE, false>(decode_tri(raw), order_base, m, tri_base + rec, lr, lrf, q, unused)) hit_any = true;
-          }
-        }
         if (MODE == Q_ANY && hit_any) {
           satisfied = true;
           cur = -1;
