@@ -21,7 +21,7 @@ struct BuildResult {
   double scale = 0.0;   // largest |coordinate|
 };
 
-// p1,p2,p3: n x 3 doubles.  max_leaf: triangles per leaf (<= 7).
+// p1,p2,p3: n x 3 doubles.  max_leaf: triangles per leaf (<= rtd::LEAF_MAX).
 void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, int max_leaf,
                BuildResult& out);
 

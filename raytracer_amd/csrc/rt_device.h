@@ -527,7 +527,7 @@ constexpr int LDS_STACK = 24;
 #define RT_STAGE_TOP 0
 #endif
 constexpr int TOP_NODES = 128;
-constexpr int COOP_SLOTS = 64 * 7;  // a leaf holds at most 7 triangles
+constexpr int COOP_SLOTS = 64 * LEAF_MAX;
 typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 struct TravStack {
@@ -759,8 +759,8 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
       }
       if (cur <= -2) {
         int code = -2 - cur;
-        const bool done = FAST ? test_leaf<MODE, STATS>(order_base, tri_base, m, trisf, code >> 3, code & 7, lr, lrf, q, cnt)
-                               : test_leaf<MODE, STATS>(order_base, tri_base, m, tris, code >> 3, code & 7, lr, lrf, q, cnt);
+        const bool done = FAST ? test_leaf<MODE, STATS>(order_base, tri_base, m, trisf, code >> LEAF_BITS, code & LEAF_MAX, lr, lrf, q, cnt)
+                               : test_leaf<MODE, STATS>(order_base, tri_base, m, tris, code >> LEAF_BITS, code & LEAF_MAX, lr, lrf, q, cnt);
         if (done) return true;
         // a leaf may have tightened the interval
         if (MODE == Q_CLOSEST) {
@@ -864,16 +864,21 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
       // ---- shared leaf phase (all 64 lanes)
       const bool has_leaf = cur <= -2;
       const int code = has_leaf ? -2 - cur : 0;
-      const int lfirst = code >> 3;
-      const int lcount = has_leaf ? (code & 7) : 0;
-      // prefix sum of the counts (3-bit numbers) from three ballots: no cross-lane data movement
-      const unsigned long long b0 = __ballot(lcount & 1), b1 = __ballot(lcount & 2), b2 = __ballot(lcount & 4);
+      const int lfirst = code >> LEAF_BITS;
+      const int lcount = has_leaf ? (code & LEAF_MAX) : 0;
+      // prefix sum of the counts (LEAF_BITS-bit numbers) from one ballot per bit: no
+      // cross-lane data movement
       const unsigned long long below = (1ull << lane) - 1ull;
-      const int off = __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
-      const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+      int off = 0, total = 0;
+#pragma unroll
+      for (int b = 0; b < LEAF_BITS; b++) {
+        const unsigned long long bal = __ballot((lcount >> b) & 1);
+        off += __popcll(bal & below) << b;
+        total += __popcll(bal) << b;
+      }
       bool hit_any = false;
 #pragma unroll
-      for (int j = 0; j < 7; j++)
+      for (int j = 0; j < LEAF_MAX; j++)  // predicated stores; a loop bounded by a ballot measured slower
         if (j < lcount) st.owners[off + j] = (unsigned char)lane;
       for (int base = 0; base < total; base += 64) {  // wave-uniform
         const int s = base + lane;

@@ -53,7 +53,9 @@ struct alignas(8) DTriN {
 // Box planes are 16-bit steps of a grid laid over the mesh's padded bounds (DMesh lo/cell),
 // rounded outward: q[a] = lo_q | hi_q << 16 for child 0 on axis a, q[3+a] for child 1.
 // Child c >= 0: inner node index; c == -1: no child; c <= -2: leaf, code = -2 - c =
-// (first << 3) | count with `first` relative to the mesh's tri_base and count <= 7.
+// (first << LEAF_BITS) | count with `first` relative to the mesh's tri_base.
+constexpr int LEAF_BITS = 4;                       // bits of a leaf code that hold the count
+constexpr int LEAF_MAX = (1 << LEAF_BITS) - 1;     // most triangles one leaf can hold
 struct alignas(32) DNode {
   uint32_t q[6];
   int32_t c0, c1;

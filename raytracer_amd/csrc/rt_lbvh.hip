@@ -261,12 +261,12 @@ __global__ void k_emit_nodes(const unsigned long long* keys, const Box6* tri_box
         b[a] = tb.lo[a];
         b[3 + a] = tb.hi[a];
       }
-      code = -2 - ((pos << 3) | 1);
+      code = -2 - ((pos << rtd::LEAF_BITS) | 1);
     } else {
       int c = cs[w];
       for (int k = 0; k < 6; k++) b[k] = node_boxes[6 * (size_t)c + k];
       int cnt = range_last[c] - range_first[c] + 1;
-      code = (cnt <= max_leaf) ? -2 - ((range_first[c] << 3) | cnt) : new_index[c];
+      code = (cnt <= max_leaf) ? -2 - ((range_first[c] << rtd::LEAF_BITS) | cnt) : new_index[c];
     }
     for (int a = 0; a < 3; a++) {
       unsigned lo = grid_down(G, a, b[a] - G.pad), hi = grid_up(G, a, b[3 + a] + G.pad);
@@ -306,8 +306,8 @@ int build_lbvh_device(const double* p1, const double* p2, const double* p3, int6
   out.max_depth = 0;
   out.scale = 0.0;
   for (int a = 0; a < 3; a++) out.lo[a] = out.hi[a] = out.cell[a] = 0.0;
-  max_leaf = std::max(1, std::min(max_leaf, 7));
-  if (n64 > (1 << 28)) {
+  max_leaf = std::max(1, std::min(max_leaf, rtd::LEAF_MAX));
+  if (n64 > (1 << (30 - rtd::LEAF_BITS))) {
     err = "mesh too large for the device builder";
     return 1;
   }
@@ -375,7 +375,7 @@ int build_lbvh_device(const double* p1, const double* p2, const double* p3, int6
   if (n <= max_leaf) {  // the whole mesh is one leaf
     rtd::DNode N = empty;
     for (int a = 0; a < 3; a++) N.q[a] = 0u | (65535u << 16);
-    N.c0 = -2 - ((0 << 3) | n);
+    N.c0 = -2 - ((0 << rtd::LEAF_BITS) | n);
     out.nodes.push_back(N);
     out.max_depth = 1;
     return 0;
