@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--pipeline", default="wavefront", choices=["megakernel", "wavefront"])
     ap.add_argument("--mode", default="f64_parity", choices=["f64_parity", "f32_fast"],
                     help="f32_fast: triangle search in f32, everything else f64; reported with its pixel-match rate")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="frames in flight: step k is issued on stream k %% inflight with its own buffers, so the "
+                         "tail of one frame's recursion level runs under the next frame (1 = strictly one at a time)")
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="host binned-SAH or device LBVH build")
     ap.add_argument("--cpu-pixels", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,38 +145,46 @@ def main():
     mode = rt.MODE_F32_FAST if args.mode == "f32_fast" else rt.MODE_F64_PARITY
     w = rt.World.example(example, hs, vs, synthetic_tris=ntris).commit(device=dev.index, bvh_builder=1 if args.bvh == "lbvh" else 0)
     info = w.info()
-    stream = torch.cuda.current_stream().cuda_stream
+    F = max(1, args.inflight)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
 
     n = world_size
     per = max(rt.shard_tiles(hs, vs, s, n) for s in range(n))
-    image = torch.zeros((vs, hs, 3), dtype=torch.uint8, device=dev)
-    tiles = torch.zeros(per * rt.TILE * rt.TILE * 3, dtype=torch.uint8, device=dev) if n > 1 else None
+    images = [torch.zeros((vs, hs, 3), dtype=torch.uint8, device=dev) for _ in range(F)]
+    tiles = [torch.zeros(per * rt.TILE * rt.TILE * 3, dtype=torch.uint8, device=dev) for _ in range(F)] if n > 1 else None
     # rank 0 receives every shard straight into its row of one contiguous buffer
-    all_tiles = torch.zeros((n, per * rt.TILE * rt.TILE * 3), dtype=torch.uint8, device=dev) if (n > 1 and rank == 0) else None
-    gathered = list(all_tiles.unbind(0)) if all_tiles is not None else None
+    all_tiles = [torch.zeros((n, per * rt.TILE * rt.TILE * 3), dtype=torch.uint8, device=dev) for _ in range(F)] \
+        if (n > 1 and rank == 0) else None
+    image = images[0]
 
-    def exchange():
+    def exchange(slot):
         """The one exchange step: shards -> rank 0 (RCCL gather), de-tile kernel there."""
+        stream = torch.cuda.current_stream().cuda_stream
         if rehearsal:
-            h = [torch.zeros(tiles.numel(), dtype=torch.uint8) for _ in range(n)] if rank == 0 else None
-            dist.gather(tiles.cpu(), h, dst=0)
+            h = [torch.zeros(tiles[slot].numel(), dtype=torch.uint8) for _ in range(n)] if rank == 0 else None
+            dist.gather(tiles[slot].cpu(), h, dst=0)
             if rank == 0:
-                all_tiles.copy_(torch.stack(h))
+                all_tiles[slot].copy_(torch.stack(h))
         else:
-            dist.gather(tiles, gathered, dst=0)
+            dist.gather(tiles[slot], list(all_tiles[slot].unbind(0)) if rank == 0 else None, dst=0)
         if rank == 0:
-            rt.detile_u8(all_tiles.data_ptr(), n, per, hs, vs, image.data_ptr(), stream)
+            rt.detile_u8(all_tiles[slot].data_ptr(), n, per, hs, vs, images[slot].data_ptr(), stream)
 
-    def step(want_stats=False):
-        if n == 1:
-            w.render_device(d_u8=image.data_ptr(), stream=stream, pipeline=pipeline, mode=mode, want_stats=want_stats)
-        else:
-            w.render_device(d_u8=tiles.data_ptr(), stream=stream, pipeline=pipeline, mode=mode, tile_first=rank,
-                            tile_step=n, want_stats=want_stats)
-            exchange()
+    def step(k=0, want_stats=False):
+        """Frame k: rendered (and, for n > 1, exchanged) on stream k % F with that slot's buffers."""
+        slot = k % F
+        with torch.cuda.stream(streams[slot]):
+            stream = streams[slot].cuda_stream
+            if n == 1:
+                w.render_device(d_u8=images[slot].data_ptr(), stream=stream, pipeline=pipeline, mode=mode,
+                                want_stats=want_stats)
+            else:
+                w.render_device(d_u8=tiles[slot].data_ptr(), stream=stream, pipeline=pipeline, mode=mode,
+                                tile_first=rank, tile_step=n, want_stats=want_stats)
+                exchange(slot)
 
     # counters of one frame (outside the timed region; deterministic per scene)
-    step(want_stats=True)
+    step(0, want_stats=True)
     torch.cuda.synchronize()
     st = w.stats().as_dict()
     keys = ["rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "depth0_skipped", "pred_queries",
@@ -183,32 +194,29 @@ def main():
         st.update({k: int(v) for k, v in zip(keys, t.tolist())})
     rays_per_frame = st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"] + st["rays_refract"]
 
-    for _ in range(args.warmup):
-        step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for k in range(max(args.warmup, F)):  # at least one frame per slot, so every slot's queues are sized
+        step(k)
     torch.cuda.synchronize()
+    # latency of one frame alone (not part of the timed region)
+    t0 = time.perf_counter()
+    step(0)
+    torch.cuda.synchronize()
+    frame_latency_ms = (time.perf_counter() - t0) * 1e3
     if n > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        if n == 1:
-            step()
-            ev[i][1].record()
-        else:
-            w.render_device(d_u8=tiles.data_ptr(), stream=stream, pipeline=pipeline, mode=mode, tile_first=rank, tile_step=n)
-            ev[i][1].record()
-            exchange()
+    for k in range(args.steps):
+        step(k)
     torch.cuda.synchronize()
     if n > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # this rank's render kernel(s)
+    kernel_ms = elapsed * 1e3 / args.steps  # with frames in flight the kernels of neighbouring frames overlap
     if n > 1:
-        t = all_reduce(torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
-        elapsed, kernel_ms = t.tolist()
+        t = all_reduce(torch.tensor([elapsed, kernel_ms, frame_latency_ms], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
+        elapsed, kernel_ms, frame_latency_ms = t.tolist()
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -227,7 +235,7 @@ def main():
             "scaling": "strong", "vs_baseline": None,
             "dtype": "f64" if args.mode == "f64_parity" else "f32 triangle search + f64 shading", "data": "synthetic",
             "config": {"workload": desc, "hsize": hs, "vsize": vs, "depth": 5, "mode": args.mode,
-                       "pipeline": args.pipeline, "bvh": args.bvh, "commit_ms": info["commit_ms"], "rays_per_frame": rays_per_frame,
+                       "pipeline": args.pipeline, "frames_in_flight": F, "frame_latency_ms": frame_latency_ms, "bvh": args.bvh, "commit_ms": info["commit_ms"], "rays_per_frame": rays_per_frame,
                        "parallelism": f"tiles{rt.TILE}x{rt.TILE} round-robin over {n} GPU(s)" + (", RCCL gather to rank 0" if n > 1 else ""),
                        "triangles": info["n_triangles"], "bvh_nodes": info["n_bvh_nodes"],
                        "scene_bytes": info["device_bytes"], "frame_crc32": frame_crc},
@@ -248,7 +256,7 @@ def main():
         if args.mode == "f32_fast" and n == 1:
             # the fast mode is reported with its pixel-match rate against the parity mode's frame
             fast = image.cpu().numpy().astype(np.int16)
-            w.render_device(d_u8=image.data_ptr(), stream=stream, pipeline=pipeline, mode=rt.MODE_F64_PARITY)
+            w.render_device(d_u8=image.data_ptr(), stream=streams[0].cuda_stream, pipeline=pipeline, mode=rt.MODE_F64_PARITY)
             torch.cuda.synchronize()
             d = np.abs(fast - image.cpu().numpy().astype(np.int16)).max(axis=-1)
             out["pixel_match_vs_f64_parity"] = {"exact": float((d == 0).mean()), "within_1": float((d <= 1).mean()),

@@ -63,12 +63,18 @@ struct rt_scene {
   uint8_t* d_out_u8 = nullptr;
   size_t out_cap_px = 0;
   // wavefront pipeline: per-level ray queues and result nodes (grow only)
-  void* wf_tasks[MAX_DEPTH + 1] = {};
-  void* wf_nodes[MAX_DEPTH + 1] = {};
-  size_t wf_task_cap[MAX_DEPTH + 1] = {};
-  size_t wf_node_cap[MAX_DEPTH + 1] = {};
-  unsigned int* wf_counts = nullptr;       // device, two counters per level
-  unsigned int* wf_counts_host = nullptr;  // pinned
+  // One set per stream that renders with the wavefront pipeline, so that frames issued on
+  // different streams may overlap (the tail of one frame's level under the next frame).
+  struct WfState {
+    hipStream_t stream = nullptr;
+    void* wf_tasks[MAX_DEPTH + 1] = {};
+    void* wf_nodes[MAX_DEPTH + 1] = {};
+    size_t wf_task_cap[MAX_DEPTH + 1] = {};
+    size_t wf_node_cap[MAX_DEPTH + 1] = {};
+    unsigned int* wf_counts = nullptr;       // device, two counters per level
+    unsigned int* wf_counts_host = nullptr;  // pinned
+  };
+  std::vector<WfState*> wf_states;  // at most WF_MAX_STREAMS; beyond that streams share the last one
   // queue lengths of the last frame rendered with host read-backs: the same frame (camera,
   // shard, depth, mode) is then issued again without any synchronisation
   // Wavefront kernels share the triangle tests of a wave's leaves between all its lanes
@@ -562,12 +568,15 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->d_out_u8) (void)hipFree(s->d_out_u8);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
-    for (int l = 0; l <= MAX_DEPTH; l++) {
-      if (s->wf_tasks[l]) (void)hipFree(s->wf_tasks[l]);
-      if (s->wf_nodes[l]) (void)hipFree(s->wf_nodes[l]);
+    for (rt_scene::WfState* w : s->wf_states) {
+      for (int l = 0; l <= MAX_DEPTH; l++) {
+        if (w->wf_tasks[l]) (void)hipFree(w->wf_tasks[l]);
+        if (w->wf_nodes[l]) (void)hipFree(w->wf_nodes[l]);
+      }
+      if (w->wf_counts) (void)hipFree(w->wf_counts);
+      if (w->wf_counts_host) (void)hipHostFree(w->wf_counts_host);
+      delete w;
     }
-    if (s->wf_counts) (void)hipFree(s->wf_counts);
-    if (s->wf_counts_host) (void)hipHostFree(s->wf_counts_host);
     (void)hipSetDevice(cur);
   }
   delete s;
@@ -931,11 +940,27 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
                             bool fast) {
   const uint64_t key = frame_key(dc, pm, depth, fast);
   const bool planned = (key == s->wf_plan_key);
-  if (!s->wf_counts) {
-    HIP_TRY(hipMalloc(&s->wf_counts, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int)));
-    HIP_TRY(hipHostMalloc(&s->wf_counts_host, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int)));
+  rt_scene::WfState* w = nullptr;
+  for (rt_scene::WfState* c : s->wf_states)
+    if (c->stream == st) w = c;
+  if (!w) {
+    constexpr size_t WF_MAX_STREAMS = 4;
+    if (s->wf_states.size() < WF_MAX_STREAMS) {
+      w = new rt_scene::WfState;
+      w->stream = st;
+      s->wf_states.push_back(w);
+    } else {
+      // more streams than buffer sets: order this one behind the set's previous user
+      w = s->wf_states.back();
+      HIP_TRY(hipStreamSynchronize(w->stream));
+      w->stream = st;
+    }
   }
-  HIP_TRY(hipMemsetAsync(s->wf_counts, 0, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int), st));
+  if (!w->wf_counts) {
+    HIP_TRY(hipMalloc(&w->wf_counts, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int)));
+    HIP_TRY(hipHostMalloc(&w->wf_counts_host, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int)));
+  }
+  HIP_TRY(hipMemsetAsync(w->wf_counts, 0, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int), st));
   long long n = ntiles * (RT_TILE * RT_TILE);
   long long n_front = n;     // level 0 has no queue
   unsigned int cap_in = 0;
@@ -944,18 +969,18 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
   int rc;
   for (int l = 0; l < depth; l++) {
     bool spawn = (l + 1 < depth);
-    if ((rc = wf_ensure(&s->wf_nodes[l], &s->wf_node_cap[l], (size_t)n, sizeof(WfNode)))) return rc;
+    if ((rc = wf_ensure(&w->wf_nodes[l], &w->wf_node_cap[l], (size_t)n, sizeof(WfNode)))) return rc;
     if (spawn) {
       if (2 * n > 0xfffffff0LL) return fail(RT_ERR_UNSUPPORTED, "ray queue exceeds 2^32 entries");
-      if ((rc = wf_ensure(&s->wf_tasks[l + 1], &s->wf_task_cap[l + 1], (size_t)(2 * n), sizeof(WfTask))))
+      if ((rc = wf_ensure(&w->wf_tasks[l + 1], &w->wf_task_cap[l + 1], (size_t)(2 * n), sizeof(WfTask))))
         return rc;
     }
     dim3 grid((unsigned)((n + WF_BLOCK - 1) / WF_BLOCK)), block(WF_BLOCK);
-    const WfTask* tin = static_cast<const WfTask*>(s->wf_tasks[l]);
-    WfNode* nodes = static_cast<WfNode*>(s->wf_nodes[l]);
-    WfTask* tnext = spawn ? static_cast<WfTask*>(s->wf_tasks[l + 1]) : nullptr;
-    unsigned int cap = spawn ? (unsigned int)std::min<size_t>(s->wf_task_cap[l + 1], 0xffffffffu) : 0u;
-    unsigned int* cnt_next = s->wf_counts + 2 * (l + 1);
+    const WfTask* tin = static_cast<const WfTask*>(w->wf_tasks[l]);
+    WfNode* nodes = static_cast<WfNode*>(w->wf_nodes[l]);
+    WfTask* tnext = spawn ? static_cast<WfTask*>(w->wf_tasks[l + 1]) : nullptr;
+    unsigned int cap = spawn ? (unsigned int)std::min<size_t>(w->wf_task_cap[l + 1], 0xffffffffu) : 0u;
+    unsigned int* cnt_next = w->wf_counts + 2 * (l + 1);
 #define WF_LAUNCH(ST, PR, FA, CO)                                                                        \
   hipLaunchKernelGGL((k_wf_level<ST, PR, FA, CO>), grid, block, 0, st, s->d, dc, pm, tin, n, n_front, cap_in, \
                      nodes, tnext, cnt_next, cap, spawn ? 1 : 0, s->d_counters)
@@ -987,11 +1012,11 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
       n = s->wf_plan_n[l + 1];
       n_front = s->wf_plan_front[l + 1];
     } else {
-      HIP_TRY(hipMemcpyAsync(s->wf_counts_host + 2 * (l + 1), cnt_next, 2 * sizeof(unsigned int),
+      HIP_TRY(hipMemcpyAsync(w->wf_counts_host + 2 * (l + 1), cnt_next, 2 * sizeof(unsigned int),
                              hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      n_front = s->wf_counts_host[2 * (l + 1)];
-      n = n_front + s->wf_counts_host[2 * (l + 1) + 1];
+      n_front = w->wf_counts_host[2 * (l + 1)];
+      n = n_front + w->wf_counts_host[2 * (l + 1) + 1];
       s->wf_plan_n[l + 1] = n;
       s->wf_plan_front[l + 1] = n_front;
     }
@@ -1005,12 +1030,12 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
   for (int l = levels - 1; l >= 0; l--) {
     long long m = level_n[l];
     dim3 block(256), grid((unsigned)((m + 255) / 256));
-    const WfNode* nodes = static_cast<const WfNode*>(s->wf_nodes[l]);
+    const WfNode* nodes = static_cast<const WfNode*>(w->wf_nodes[l]);
     if (l == 0)
       hipLaunchKernelGGL(k_wf_combine<true>, grid, block, 0, st, nodes, m, (WfNode*)nullptr, d_f64, d_u8);
     else
       hipLaunchKernelGGL(k_wf_combine<false>, grid, block, 0, st, nodes, m,
-                         static_cast<WfNode*>(s->wf_nodes[l - 1]), d_f64, d_u8);
+                         static_cast<WfNode*>(w->wf_nodes[l - 1]), d_f64, d_u8);
     HIP_TRY(hipGetLastError());
     s->launches++;
   }

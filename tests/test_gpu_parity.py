@@ -187,6 +187,24 @@ def test_f32_fast_mode_match_rate(rt, O, name, size, pipeline):
         w.render(mode=rt.MODE_F32_FAST, pipeline=rt.PIPELINE_MEGAKERNEL)
 
 
+def test_frames_in_flight_on_several_streams(rt, pipeline):
+    """Frames issued back to back on different streams overlap on the GPU (each stream has its
+    own ray queues); every one of them must be the frame a lone render produces."""
+    import torch
+    w = rt.World.example("pawn", 640, 360).commit()
+    ref, _, _ = w.render()
+    streams = [torch.cuda.Stream() for _ in range(5)]  # more streams than buffer sets
+    outs = [torch.zeros((360, 640, 3), dtype=torch.uint8, device="cuda") for _ in range(10)]
+    for rep in range(2):
+        for k, out in enumerate(outs):
+            st = streams[k % len(streams)]
+            w.render_device(d_u8=out.data_ptr(), stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        for out in outs:
+            assert np.array_equal(out.cpu().numpy(), ref)
+            out.zero_()
+
+
 # ---- random and adversarial scenes -------------------------------------------------------------
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_scenes(rt, O, seed):
