@@ -5,19 +5,21 @@ import torch
 import raytracer_amd as rt
 name, hs, vs = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else ("pawn", 1920, 1080)
 w = rt.World.example(name, hs, vs).commit()
-stream = torch.cuda.current_stream().cuda_stream
+F = int(os.environ.get("INFLIGHT", "3"))
+streams = [torch.cuda.Stream() for _ in range(F)]
 for n in (1, 2, 4, 8):
     per = max(rt.shard_tiles(hs, vs, s, n) for s in range(n))
-    buf = torch.zeros(per * rt.TILE * rt.TILE * 3 if n > 1 else hs * vs * 3, dtype=torch.uint8, device="cuda")
+    bufs = [torch.zeros(per * rt.TILE * rt.TILE * 3 if n > 1 else hs * vs * 3, dtype=torch.uint8, device="cuda")
+            for _ in range(F)]
     worst = 0.0
     times = []
     for r in range(n):
-        for _ in range(3):
-            w.render_device(d_u8=buf.data_ptr(), stream=stream, tile_first=r, tile_step=n)
+        for k in range(2 * F):
+            w.render_device(d_u8=bufs[k % F].data_ptr(), stream=streams[k % F].cuda_stream, tile_first=r, tile_step=n)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(20):
-            w.render_device(d_u8=buf.data_ptr(), stream=stream, tile_first=r, tile_step=n)
+        for k in range(20):
+            w.render_device(d_u8=bufs[k % F].data_ptr(), stream=streams[k % F].cuda_stream, tile_first=r, tile_step=n)
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) / 20 * 1e3)
         worst = max(times)
