@@ -338,6 +338,42 @@ constexpr int WF_BLOCK = 64;
 #ifndef WF_WAVES
 #define WF_WAVES 4
 #endif
+// One node on the way back up: ret = shade_hit's final expression (world.rs:57-64); level 0
+// writes the pixel (canvas.rs:21 + color.rs:148-155), other levels hand `ret * coef`
+// (world.rs:85 / 112) to the parent's slot.
+template <bool LEVEL0>
+__device__ __forceinline__ void combine_node(const WfNode& N, WfNode* parents, double* out_f64,
+                                             uint8_t* out_u8) {
+  if (N.parent < 0) return;
+  C3 ret = {0.0, 0.0, 0.0};
+  bool hit = N.flags & 1u;
+  if (hit) {
+    C3 s = {N.surface[0], N.surface[1], N.surface[2]};
+    C3 rl = {N.reflected[0], N.reflected[1], N.reflected[2]};
+    C3 rr = {N.refracted[0], N.refracted[1], N.refracted[2]};
+    ret = combine(s, rl, rr, (N.flags & 2u) != 0, N.reflectance);
+  }
+  if (LEVEL0) {
+    long long oi = N.parent;
+    if (out_f64) {
+      out_f64[oi * 3 + 0] = ret.r;
+      out_f64[oi * 3 + 1] = ret.g;
+      out_f64[oi * 3 + 2] = ret.b;
+    }
+    if (out_u8) {
+      out_u8[oi * 3 + 0] = quantise(ret.r);
+      out_u8[oi * 3 + 1] = quantise(ret.g);
+      out_u8[oi * 3 + 2] = quantise(ret.b);
+    }
+  } else if (hit) {
+    WfNode& P = parents[N.parent];
+    double* dst = (N.flags & 4u) ? P.refracted : P.reflected;
+    dst[0] = ret.r * N.coef;
+    dst[1] = ret.g * N.coef;
+    dst[2] = ret.b * N.coef;
+  }
+}
+
 // Fills the level's result node and appends the child rays to the next level's queue:
 // reflected rays from the front, refracted rays from the back (world.rs:78-114).
 template <bool STATS>
@@ -396,8 +432,8 @@ __device__ __forceinline__ void emit_result(const ShadeOut& so, const C3& surfac
 template <bool STATS, bool PRIMARY, bool FAST, bool COOP>
 __global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
 k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n, long long n_front,
-           unsigned int cap, WfNode* nodes, WfTask* next, unsigned int* next_count,
-           unsigned int next_cap, int spawn, unsigned long long* counters) {
+           unsigned int cap, WfNode* nodes, WfNode* direct_parents, WfTask* next,
+           unsigned int* next_count, unsigned int next_cap, int spawn, unsigned long long* counters) {
   static_assert(WF_BLOCK == 64, "the traversal stack is laid out for 64-lane blocks");
   RT_TRAV_STACK_COOP(st, S);
   Counters cnt{};
@@ -487,47 +523,23 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
       }
     }
   }
-  if (PRIMARY || active) nodes[i] = nd;
+  if (!PRIMARY && direct_parents != nullptr) {
+    // deepest level: nothing will be added to this node, so its result goes straight into
+    // the parent's slot (the same expression k_wf_combine would evaluate on the stored node)
+    if (active) combine_node<false>(nd, direct_parents, nullptr, nullptr);
+  } else if (PRIMARY || active) {
+    nodes[i] = nd;
+  }
   flush_counters<STATS>(cnt, counters);
 }
 
-// One level of the way back up: ret = shade_hit's final expression (world.rs:57-64); level 0
-// writes the pixel (canvas.rs:21 + color.rs:148-155), other levels hand `ret * coef`
-// (world.rs:85 / 112) to the parent's slot.
+// One level of the way back up (see k_wf_combine below).
 template <bool LEVEL0>
 __global__ void k_wf_combine(const WfNode* nodes, long long n, WfNode* parents, double* out_f64,
                              uint8_t* out_u8) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const WfNode& N = nodes[i];
-  if (N.parent < 0) return;
-  C3 ret = {0.0, 0.0, 0.0};
-  bool hit = N.flags & 1u;
-  if (hit) {
-    C3 s = {N.surface[0], N.surface[1], N.surface[2]};
-    C3 rl = {N.reflected[0], N.reflected[1], N.reflected[2]};
-    C3 rr = {N.refracted[0], N.refracted[1], N.refracted[2]};
-    ret = combine(s, rl, rr, (N.flags & 2u) != 0, N.reflectance);
-  }
-  if (LEVEL0) {
-    long long oi = N.parent;
-    if (out_f64) {
-      out_f64[oi * 3 + 0] = ret.r;
-      out_f64[oi * 3 + 1] = ret.g;
-      out_f64[oi * 3 + 2] = ret.b;
-    }
-    if (out_u8) {
-      out_u8[oi * 3 + 0] = quantise(ret.r);
-      out_u8[oi * 3 + 1] = quantise(ret.g);
-      out_u8[oi * 3 + 2] = quantise(ret.b);
-    }
-  } else if (hit) {
-    WfNode& P = parents[N.parent];
-    double* dst = (N.flags & 4u) ? P.refracted : P.reflected;
-    dst[0] = ret.r * N.coef;
-    dst[1] = ret.g * N.coef;
-    dst[2] = ret.b * N.coef;
-  }
+  combine_node<LEVEL0>(nodes[i], parents, out_f64, out_u8);
 }
 
 
@@ -966,6 +978,7 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
   unsigned int cap_in = 0;
   long long level_n[MAX_DEPTH + 1];
   int levels = 0;
+  bool direct_last = false;
   int rc;
   for (int l = 0; l < depth; l++) {
     bool spawn = (l + 1 < depth);
@@ -981,9 +994,12 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     WfTask* tnext = spawn ? static_cast<WfTask*>(w->wf_tasks[l + 1]) : nullptr;
     unsigned int cap = spawn ? (unsigned int)std::min<size_t>(w->wf_task_cap[l + 1], 0xffffffffu) : 0u;
     unsigned int* cnt_next = w->wf_counts + 2 * (l + 1);
+    // the deepest level writes into its parents directly and needs no pass of its own on the way up
+    WfNode* direct = (!spawn && l > 0) ? static_cast<WfNode*>(w->wf_nodes[l - 1]) : nullptr;
+    if (direct) direct_last = true;
 #define WF_LAUNCH(ST, PR, FA, CO)                                                                        \
   hipLaunchKernelGGL((k_wf_level<ST, PR, FA, CO>), grid, block, 0, st, s->d, dc, pm, tin, n, n_front, cap_in, \
-                     nodes, tnext, cnt_next, cap, spawn ? 1 : 0, s->d_counters)
+                     nodes, direct, tnext, cnt_next, cap, spawn ? 1 : 0, s->d_counters)
 #define WF_LAUNCH2(ST, PR)              \
   do {                                  \
     if (fast && s->share_leaves)        \
@@ -1027,7 +1043,7 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     s->wf_plan_key = key;
     s->wf_plan_levels = levels;
   }
-  for (int l = levels - 1; l >= 0; l--) {
+  for (int l = levels - 1 - (direct_last ? 1 : 0); l >= 0; l--) {
     long long m = level_n[l];
     dim3 block(256), grid((unsigned)((m + 255) / 256));
     const WfNode* nodes = static_cast<const WfNode*>(w->wf_nodes[l]);
