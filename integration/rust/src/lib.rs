@@ -1,7 +1,7 @@
 //! `repr(C)` mirrors of include/rt_core.h and a safe builder on top of them.
 //!
 //! The reference side implements `Flatten` for its shapes (one added trait method on
-//! `Intersectable`) and calls `render_on_gpu` where it calls
+//! `Intersectable`) and calls `Scene::render_rgb8` where it calls
 //! `scene::camera::render` today (src/main.rs:53).
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};

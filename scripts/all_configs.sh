@@ -1,5 +1,5 @@
 #!/bin/bash
-# every BASELINE config, both pipelines, one frame at a time and three frames in flight
+# every benchmark configuration, both pipelines, one frame at a time and three frames in flight
 for W in cover400 pawn1080 teaset1080 pawn8k synthetic4k; do
 for P in wavefront megakernel; do
 for F in 1 3; do

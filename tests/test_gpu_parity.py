@@ -1,7 +1,7 @@
 """Parity of the HIP render core (through the C ABI) with the CPU oracle and with the
 reference's own committed renders.  All tests need an MI355X: `pytest -m gpu`.
 
-Bars (BASELINE.json north_star): after 8-bit quantisation >= 99.9 % of the pixels equal,
+Bars: after 8-bit quantisation >= 99.9 % of the pixels equal,
 <= 1/255 on the rest.  The f64 path reaches more: geometry decisions are bit-identical, so
 every pixel is equal; the f64 colours differ from the oracle's only through pow() in the
 specular term (device libm vs glibc), bounded here by 1e-12.
@@ -54,7 +54,7 @@ def test_default_size_render_equals_reference_png(rt, O, name):
     assert exact == 1.0
 
 
-# ---- BASELINE.json configs against the oracle ---------------------------------------------
+# ---- the benchmark configurations against the oracle ---------------------------------------------
 def test_cover_400_full_image_and_counters(rt, O):
     w = rt.World.example("cover", 400, 400).commit()
     u8, f64, st = w.render(want_f64=True, want_stats=True)
