@@ -504,7 +504,8 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
     }
     bool tf = false;
     if (S.n_meshes > 0)
-      tf = tri_predecessor_coop<STATS, FAST>(S, ray, K, h.prim >= 0 ? -1 : h.tri, need, tb, tm, cnt, st);
+      tf = tri_predecessor_coop<STATS, FAST>(S, ray, predecessor_bound(K), h.prim >= 0 ? -1 : h.tri, need, tb,
+                                             tm, cnt, st);
     if (hit) {
       const DMaterial& M = S.mats[pr.mat_index];
       double n1 = 1.0, n2 = 1.0;

@@ -1040,6 +1040,18 @@ __device__ inline bool trace_any(const DScene& S, const Ray& ray, double distanc
   return traverse_meshes<Q_ANY, STATS, FAST>(S, ray, q, cnt, st);
 }
 
+// The key a predecessor query actually has to search below.  The hit is the smallest
+// (t, leaf order) over t > 0 of ALL shapes (intersect.rs:125-139), and the trigger K is that
+// hit or, for a closed-form shape, an entry of it within EPSILON below; so no triangle
+// intersects the ray anywhere in 0 < t with a key below K: it would have been the hit.  With
+// K.t > 0 the triangle predecessor is therefore the largest key with t <= 0 — the nearest
+// intersection behind the origin, ties to the highest leaf order — and the walk can skip the
+// whole stretch between the origin and the hit.
+__device__ __forceinline__ Key predecessor_bound(const Key& K) {
+  if (K.t > 0.0) return Key{0.0, 0xffffffffu, 0};
+  return K;
+}
+
 // Largest key below K among all triangle intersections of the infinite line (t may be
 // negative).  Every triangle is its own shape with at most one entry, so this is the last
 // triangle still "open" when the containers walk of intersect.rs:188-222 reaches K.
@@ -1268,7 +1280,8 @@ __device__ inline void containers_n1_n2(const DScene& S, const Ray& ray, const H
   Key K = trigger_key(S, ray, h);
   Key tb{0.0, 0u, 0};
   int tm = -1;
-  bool tf = (S.n_meshes > 0) && tri_predecessor<STATS, FAST>(S, ray, K, h.prim >= 0 ? -1 : h.tri, tb, tm, cnt, st);
+  bool tf = (S.n_meshes > 0) &&
+            tri_predecessor<STATS, FAST>(S, ray, predecessor_bound(K), h.prim >= 0 ? -1 : h.tri, tb, tm, cnt, st);
   containers_from<STATS>(S, ray, h, K, own_ri, tf, tb, tm, n1, n2, cnt);
 }
 
