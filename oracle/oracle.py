@@ -407,3 +407,11 @@ def golden_image(name):
     img = read_png_rgb8(os.path.join(REPO, "tests", "golden", fn))
     assert img.shape == (h, w, 3)
     return img
+
+
+def write_ppm(path, rgb):
+    """P3 file in the reference's layout (canvas.rs:29-44) from an HxWx3 uint8 array."""
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = a.shape[0], a.shape[1]
+    if lib().orc_write_ppm(path.encode(), w, h, a.ctypes.data_as(C.POINTER(C.c_uint8))) != 0:
+        raise OSError(f"could not write {path}")

@@ -205,7 +205,7 @@ struct RenderOptions {
   int device = -1;  // takes the place of `thread_count` (camera.rs:83): which GPU renders
   int depth = 5;    // camera.rs:178
   int mode = RT_MODE_F64_PARITY;
-  int pipeline = RT_PIPELINE_MEGAKERNEL;
+  int pipeline = RT_PIPELINE_WAVEFRONT;
   bool keep_f64 = false;
   rt_stats* stats = nullptr;
 };

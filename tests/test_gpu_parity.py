@@ -205,6 +205,27 @@ def test_frames_in_flight_on_several_streams(rt, pipeline):
             out.zero_()
 
 
+def test_cli_writes_the_reference_ppm(rt, O, tmp_path, pipeline):
+    """rt_cli (the reference's command line, main.rs:13-55, on the GPU core): the P3 file it
+    writes equals the oracle's writer (canvas.rs:29-44) on the oracle's frame, byte for byte."""
+    import os
+    import subprocess
+    if pipeline != "wavefront":
+        pytest.skip("the command line has one pipeline")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "cli.ppm"
+    r = subprocess.run([os.path.join(repo, "raytracer_amd", "rt_cli"), "-e", "pawn", "-t", "6", "--width", "160",
+                        "--height", "90", "--obj-dir", os.path.join(repo, "assets", "obj"), "--out", str(out),
+                        "--stats"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "Rendering image" in r.stdout and "Mrays/s" in r.stdout
+    _, ou8, _ = O.Scene.example("pawn", 160, 90).render()
+    want = tmp_path / "oracle.ppm"
+    O.write_ppm(str(want), ou8)
+    assert out.read_bytes() == want.read_bytes()
+    assert out.read_bytes().startswith(b"P3\n160 90\n255\n")
+
+
 # ---- random and adversarial scenes -------------------------------------------------------------
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_scenes(rt, O, seed):
