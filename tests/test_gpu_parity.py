@@ -34,12 +34,12 @@ def u8_report(a, b):
     return float((d == 0).mean()), int(d.max())
 
 
-def build_both(rt, O, builder, *args, **kw):
+def build_both(rt, O, builder, *args, bvh_builder=0, **kw):
     w = rt.World()
     builder(w, rt.material, rt, *args, **kw)
     s = O.Scene()
     builder(s, O.material, rt, *args, **kw)  # same matrices (product's host math) on both sides
-    w.commit()
+    w.commit(bvh_builder=bvh_builder)
     return w, s
 
 
@@ -233,6 +233,19 @@ def test_random_scenes(rt, O, seed):
     u8, f64, _ = w.render(want_f64=True)
     of64, ou8, cnt = s.render()
     assert cnt["nan_t"] == 0
+    assert np.array_equal(u8, ou8)
+    assert np.abs(f64 - of64).max() <= 1e-11
+
+
+@pytest.mark.parametrize("n_tris", [1, 2, 3, 13, 16, 17, 400])
+@pytest.mark.parametrize("bvh_builder", [0, 1])
+def test_mesh_sizes_around_the_leaf_limits(rt, O, n_tris, bvh_builder):
+    """Meshes of one triangle, of exactly one leaf, of one leaf plus one, ... with both BVH
+    builders: single-leaf roots, empty child slots and the largest leaves."""
+    w, s = build_both(rt, O, scenes.random_scene, 40 + n_tris, n_prims=3, n_tris=n_tris, hsize=72, vsize=48,
+                      bvh_builder=bvh_builder)
+    u8, f64, _ = w.render(want_f64=True)
+    of64, ou8, cnt = s.render()
     assert np.array_equal(u8, ou8)
     assert np.abs(f64 - of64).max() <= 1e-11
 
