@@ -156,6 +156,9 @@ def main():
     all_tiles = [torch.zeros((n, per * rt.TILE * rt.TILE * 3), dtype=torch.uint8, device=dev) for _ in range(F)] \
         if (n > 1 and rank == 0) else None
     image = images[0]
+    exchange_mode = ["gather"]
+    everyone = [torch.zeros(n * per * rt.TILE * rt.TILE * 3, dtype=torch.uint8, device=dev) for _ in range(F)] \
+        if n > 1 else None
 
     def exchange(slot):
         """The one exchange step: shards -> rank 0 (RCCL gather), de-tile kernel there."""
@@ -165,8 +168,16 @@ def main():
             dist.gather(tiles[slot].cpu(), h, dst=0)
             if rank == 0:
                 all_tiles[slot].copy_(torch.stack(h))
-        else:
-            dist.gather(tiles[slot], list(all_tiles[slot].unbind(0)) if rank == 0 else None, dst=0)
+        elif exchange_mode[0] == "gather":
+            try:
+                dist.gather(tiles[slot], list(all_tiles[slot].unbind(0)) if rank == 0 else None, dst=0)
+            except (RuntimeError, NotImplementedError):
+                # a backend without gather: every rank takes all shards instead (still one collective)
+                exchange_mode[0] = "all_gather"
+        if exchange_mode[0] == "all_gather":
+            dist.all_gather_into_tensor(everyone[slot], tiles[slot])
+            if rank == 0:
+                all_tiles[slot].copy_(everyone[slot].view_as(all_tiles[slot]))
         if rank == 0:
             rt.detile_u8(all_tiles[slot].data_ptr(), n, per, hs, vs, images[slot].data_ptr(), stream)
 
