@@ -516,7 +516,10 @@ struct HitRec {
 // their depths), deeper entries spill to a private array that well-built trees never reach.
 // The LDS pointer carries its address space so pushes and pops are plain ds_write/ds_read.
 constexpr int STACK_MAX = 64;
-constexpr int LDS_STACK = 24;
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 24
+#endif
+constexpr int LDS_STACK = RT_LDS_STACK;
 // Build option RT_STAGE_TOP=1: the top of every mesh's tree (the builders put it first,
 // breadth first) is staged in LDS once per block, TOP_NODES 32-byte nodes shared evenly by
 // the scene's meshes (none when there are more than TOP_NODES / 8 meshes).  Off by default:
@@ -877,9 +880,13 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
         total += __popcll(bal) << b;
       }
       bool hit_any = false;
+      // predicated stores, four at a time under one wave-uniform test
+      for (int j0 = 0; j0 < LEAF_MAX; j0 += 4) {
+        if (__ballot(lcount > j0) == 0ull) break;
 #pragma unroll
-      for (int j = 0; j < LEAF_MAX; j++)  // predicated stores; a loop bounded by a ballot measured slower
-        if (j < lcount) st.owners[off + j] = (unsigned char)lane;
+        for (int j = j0; j < j0 + 4; j++)
+          if (j < lcount) st.owners[off + j] = (unsigned char)lane;
+      }
       for (int base = 0; base < total; base += 64) {  // wave-uniform
         const int s = base + lane;
         const bool work = s < total;

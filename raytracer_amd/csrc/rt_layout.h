@@ -54,7 +54,10 @@ struct alignas(8) DTriN {
 // rounded outward: q[a] = lo_q | hi_q << 16 for child 0 on axis a, q[3+a] for child 1.
 // Child c >= 0: inner node index; c == -1: no child; c <= -2: leaf, code = -2 - c =
 // (first << LEAF_BITS) | count with `first` relative to the mesh's tri_base.
-constexpr int LEAF_BITS = 4;                       // bits of a leaf code that hold the count
+#ifndef RT_LEAF_BITS
+#define RT_LEAF_BITS 4
+#endif
+constexpr int LEAF_BITS = RT_LEAF_BITS;            // bits of a leaf code that hold the count
 constexpr int LEAF_MAX = (1 << LEAF_BITS) - 1;     // most triangles one leaf can hold
 struct alignas(32) DNode {
   uint32_t q[6];
