@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pawn1080", choices=sorted(WORKLOADS))
-    ap.add_argument("--pipeline", default="wavefront", choices=["megakernel", "wavefront"])
+    ap.add_argument("--pipeline", default="wavefront", choices=["megakernel", "wavefront", "auto"])
     ap.add_argument("--mode", default="f64_parity", choices=["f64_parity", "f32_fast"],
                     help="f32_fast: triangle search in f32, everything else f64; reported with its pixel-match rate")
     ap.add_argument("--inflight", type=int, default=3,
@@ -141,7 +141,8 @@ def main():
         return t
 
     example, hs, vs, ntris, desc = WORKLOADS[args.workload]
-    pipeline = {"megakernel": rt.PIPELINE_MEGAKERNEL, "wavefront": rt.PIPELINE_WAVEFRONT}[args.pipeline]
+    pipeline = {"megakernel": rt.PIPELINE_MEGAKERNEL, "wavefront": rt.PIPELINE_WAVEFRONT,
+                "auto": rt.PIPELINE_AUTO}[args.pipeline]
     mode = rt.MODE_F32_FAST if args.mode == "f32_fast" else rt.MODE_F64_PARITY
     w = rt.World.example(example, hs, vs, synthetic_tris=ntris).commit(device=dev.index, bvh_builder=1 if args.bvh == "lbvh" else 0)
     info = w.info()

@@ -56,7 +56,10 @@ enum { RT_SOLID = 0, RT_STRIPE = 1, RT_GRADIENT = 2, RT_RINGS = 3, RT_CHECKERED 
 enum { RT_MODE_F64_PARITY = 0, RT_MODE_F32_FAST = 1 };
 /* kernel organisation: one lane per pixel with an explicit recursion stack, or per-depth
  * ray queues with one fused trace+shade kernel per depth ("wavefront") */
-enum { RT_PIPELINE_MEGAKERNEL = 0, RT_PIPELINE_WAVEFRONT = 1 };
+enum { RT_PIPELINE_MEGAKERNEL = 0, RT_PIPELINE_WAVEFRONT = 1,
+       /* whichever of the two is faster for this frame: measured the first time a (camera,
+        * shard, depth) is rendered, remembered afterwards; the frames are the same bits */
+       RT_PIPELINE_AUTO = 2 };
 
 /* draw/material.rs:6-15 + the pattern it boxes (patterns.rs).  pattern_inv is the
  * pattern's inverse transform (identity for Solid, patterns.rs:42-45). */

@@ -20,6 +20,7 @@ pub const RT_MODE_F64_PARITY: c_int = 0;
 pub const RT_MODE_F32_FAST: c_int = 1;
 pub const RT_PIPELINE_MEGAKERNEL: c_int = 0;
 pub const RT_PIPELINE_WAVEFRONT: c_int = 1;
+pub const RT_PIPELINE_AUTO: c_int = 2;
 
 #[repr(C)]
 #[derive(Clone, Copy)]

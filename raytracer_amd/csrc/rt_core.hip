@@ -80,6 +80,7 @@ struct rt_scene {
   // Wavefront kernels share the triangle tests of a wave's leaves between all its lanes
   // (traverse_meshes_coop): pawn 1080p 7.0 -> 5.5 ms, tea set 1.08 -> 1.01 ms.
   // RT_SHARE_LEAVES=0 selects the per-lane leaf tests instead.
+  std::vector<std::pair<uint64_t, int>> auto_choice;  // frame key -> pipeline picked by RT_PIPELINE_AUTO
   bool share_leaves = true;
   uint64_t wf_plan_key = 0;
   int wf_plan_levels = 0;
@@ -1059,9 +1060,9 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
   return RT_OK;
 }
 
-int rt_render_device(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline,
-                     int tile_first, int tile_step, double* d_rgb_f64, uint8_t* d_rgb_u8,
-                     void* hip_stream, int want_stats) {
+static int render_device_fixed(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline,
+                               int tile_first, int tile_step, double* d_rgb_f64, uint8_t* d_rgb_u8,
+                               void* hip_stream, int want_stats) {
   if (!s || !cam) return fail(RT_ERR_ARG, "null argument");
   if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
   if (mode != RT_MODE_F64_PARITY && mode != RT_MODE_F32_FAST) return fail(RT_ERR_ARG, "unknown mode");
@@ -1108,6 +1109,57 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, int depth, int mode, int
   HIP_TRY(hipEventRecord(s->ev1, st));
   s->timing_pending = true;
   return RT_OK;
+}
+
+// RT_PIPELINE_AUTO: the first time a frame (camera, shard, depth, mode) is seen it is rendered
+// once with each pipeline and timed with HIP events (both write the same bits); the faster
+// one is remembered for that frame.
+int rt_render_device(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline,
+                     int tile_first, int tile_step, double* d_rgb_f64, uint8_t* d_rgb_u8,
+                     void* hip_stream, int want_stats) {
+  if (pipeline != RT_PIPELINE_AUTO)
+    return render_device_fixed(s, cam, depth, mode, pipeline, tile_first, tile_step, d_rgb_f64, d_rgb_u8,
+                               hip_stream, want_stats);
+  if (!s || !cam) return fail(RT_ERR_ARG, "null argument");
+  if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+  if (mode == RT_MODE_F32_FAST || depth == 0)  // one pipeline serves these
+    return render_device_fixed(s, cam, depth, mode, depth == 0 ? RT_PIPELINE_MEGAKERNEL : RT_PIPELINE_WAVEFRONT,
+                               tile_first, tile_step, d_rgb_f64, d_rgb_u8, hip_stream, want_stats);
+  DCamera dc;
+  int rc = camera_to_device(cam, dc);
+  if (rc) return rc;
+  PixelMap pm;
+  pm.hsize = cam->hsize;
+  pm.vsize = cam->vsize;
+  pm.tiles_x = (cam->hsize + RT_TILE - 1) / RT_TILE;
+  pm.tile_first = tile_first;
+  pm.tile_step = tile_step;
+  const uint64_t key = frame_key(dc, pm, depth, false);
+  for (const auto& kv : s->auto_choice)
+    if (kv.first == key)
+      return render_device_fixed(s, cam, depth, mode, kv.second, tile_first, tile_step, d_rgb_f64, d_rgb_u8,
+                                 hip_stream, want_stats);
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  float best_ms = 0.f;
+  int best = RT_PIPELINE_WAVEFRONT;
+  const int candidates[2] = {RT_PIPELINE_WAVEFRONT, RT_PIPELINE_MEGAKERNEL};
+  for (int c = 0; c < 2; c++) {
+    float ms = 0.f;
+    for (int rep = 0; rep < 2; rep++) {  // the first run of a pipeline sizes its buffers
+      rc = render_device_fixed(s, cam, depth, mode, candidates[c], tile_first, tile_step, d_rgb_f64, d_rgb_u8,
+                               hip_stream, 0);
+      if (rc) return rc;
+      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    }
+    if (c == 0 || ms < best_ms) {
+      best_ms = ms;
+      best = candidates[c];
+    }
+  }
+  s->auto_choice.push_back({key, best});
+  return render_device_fixed(s, cam, depth, mode, best, tile_first, tile_step, d_rgb_f64, d_rgb_u8, hip_stream,
+                             want_stats);
 }
 
 int rt_render_stats(rt_scene* s, rt_stats* st) {

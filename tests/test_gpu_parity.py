@@ -187,6 +187,17 @@ def test_f32_fast_mode_match_rate(rt, O, name, size, pipeline):
         w.render(mode=rt.MODE_F32_FAST, pipeline=rt.PIPELINE_MEGAKERNEL)
 
 
+def test_auto_pipeline_renders_the_same_frame(rt, O):
+    """RT_PIPELINE_AUTO times both pipelines once per frame and keeps the faster; whatever it
+    picks, the frame is the oracle's."""
+    w = rt.World.example("tea set", 320, 180).commit()
+    a, fa, _ = w.render(pipeline=rt.PIPELINE_AUTO, want_f64=True)
+    b, fb, st = w.render(pipeline=rt.PIPELINE_AUTO, want_f64=True, want_stats=True)
+    _, ou8, cnt = O.Scene.example("tea set", 320, 180).use_bvh().render()
+    assert np.array_equal(a, ou8) and np.array_equal(b, ou8) and np.array_equal(fa, fb)
+    assert st.rays_shadow == cnt["shadow"]
+
+
 def test_frames_in_flight_on_several_streams(rt, pipeline):
     """Frames issued back to back on different streams overlap on the GPU (each stream has its
     own ray queues); every one of them must be the frame a lone render produces."""
