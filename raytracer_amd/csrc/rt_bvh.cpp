@@ -202,7 +202,65 @@ void set_empty(rtd::DNode& N, int which) {
 
 }  // namespace
 
-void reorder_top_breadth_first(std::vector<rtd::DNode>& nodes, int top) {
+namespace {
+int collapse_rec(const std::vector<rtd::DNode>& in, int i, std::vector<rtd::DNode4>& out, int self) {
+  // gather up to four (box words, code) slots: a leaf child stays, an inner child gives its two
+  uint32_t q[4][3];
+  int code[4];
+  int n = 0;
+  const rtd::DNode& N = in[i];
+  const int cs[2] = {N.c0, N.c1};
+  for (int w = 0; w < 2; w++) {
+    if (cs[w] == -1) continue;
+    if (cs[w] <= -2) {
+      for (int a = 0; a < 3; a++) q[n][a] = N.q[3 * w + a];
+      code[n++] = cs[w];
+    } else {
+      const rtd::DNode& C = in[cs[w]];
+      const int gs[2] = {C.c0, C.c1};
+      for (int v = 0; v < 2; v++) {
+        if (gs[v] == -1) continue;
+        for (int a = 0; a < 3; a++) q[n][a] = C.q[3 * v + a];
+        code[n++] = gs[v];
+      }
+    }
+  }
+  int depth = 1;
+  for (int k = 0; k < 4; k++) {
+    if (k < n) {
+      for (int a = 0; a < 3; a++) out[self].q[3 * k + a] = q[k][a];
+      if (code[k] >= 0) {
+        const int child = (int)out.size();
+        out.emplace_back();
+        out[self].c[k] = child;
+        depth = std::max(depth, 1 + collapse_rec(in, code[k], out, child));
+      } else {
+        out[self].c[k] = code[k];
+      }
+    } else {
+      for (int a = 0; a < 3; a++) out[self].q[3 * k + a] = 0xffffu;  // lo = 65535, hi = 0
+      out[self].c[k] = -1;
+    }
+  }
+  return depth;
+}
+}  // namespace
+
+int collapse_to_wide(const std::vector<rtd::DNode>& nodes, std::vector<rtd::DNode4>& out) {
+  out.clear();
+  out.reserve(nodes.size() / 2 + 2);
+  out.emplace_back();
+  if (nodes.empty()) {
+    for (int k = 0; k < 4; k++) {
+      for (int a = 0; a < 3; a++) out[0].q[3 * k + a] = 0xffffu;
+      out[0].c[k] = -1;
+    }
+    return 1;
+  }
+  return collapse_rec(nodes, 0, out, 0);
+}
+
+void reorder_top_breadth_first(std::vector<rtd::DNode4>& nodes, int top) {
   const int n = (int)nodes.size();
   if (n <= 2 || top <= 1) return;
   std::vector<int> order;  // new position -> old index
@@ -211,9 +269,8 @@ void reorder_top_breadth_first(std::vector<rtd::DNode>& nodes, int top) {
   order.push_back(0);
   taken[0] = 1;
   for (size_t head = 0; head < order.size() && (int)order.size() < top; head++) {
-    const rtd::DNode& N = nodes[order[head]];
-    const int cs[2] = {N.c0, N.c1};
-    for (int c : cs)
+    const rtd::DNode4& N = nodes[order[head]];
+    for (int c : N.c)
       if (c >= 0 && c < n && !taken[c] && (int)order.size() < top) {
         order.push_back(c);
         taken[c] = 1;
@@ -223,11 +280,11 @@ void reorder_top_breadth_first(std::vector<rtd::DNode>& nodes, int top) {
     if (!taken[i]) order.push_back(i);
   std::vector<int> where(n);
   for (int k = 0; k < n; k++) where[order[k]] = k;
-  std::vector<rtd::DNode> out(n);
+  std::vector<rtd::DNode4> out(n);
   for (int k = 0; k < n; k++) {
-    rtd::DNode N = nodes[order[k]];
-    if (N.c0 >= 0) N.c0 = where[N.c0];
-    if (N.c1 >= 0) N.c1 = where[N.c1];
+    rtd::DNode4 N = nodes[order[k]];
+    for (int j = 0; j < 4; j++)
+      if (N.c[j] >= 0) N.c[j] = where[N.c[j]];
     out[k] = N;
   }
   nodes.swap(out);

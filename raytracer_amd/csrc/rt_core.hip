@@ -757,7 +757,7 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   std::vector<DTri> tris;
   std::vector<DTriF> trisf;
   std::vector<DTriN> trin;
-  std::vector<DNode> nodes;
+  std::vector<DNode4> nodes;
   int64_t total_tris = 0;
   for (const MeshH& h : s->meshes) total_tris += h.ntris;
   if (total_tris > 0x7fffff00LL) return fail(RT_ERR_UNSUPPORTED, "too many triangles");
@@ -778,9 +778,12 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     } else {
       rtb::build_sah(h.p1.data(), h.p2.data(), h.p3.data(), h.ntris, max_leaf, br);
     }
-    if (br.max_depth >= STACK_MAX - 2)
+    // the kernels walk four-wide nodes; a step leaves up to three children on the stack
+    std::vector<DNode4> wide;
+    const int wide_depth = rtb::collapse_to_wide(br.nodes, wide);
+    if (3 * wide_depth + 2 >= STACK_MAX)
       return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
-    rtb::reorder_top_breadth_first(br.nodes, TOP_NODES);
+    rtb::reorder_top_breadth_first(wide, TOP_NODES);
     DMesh& M = meshes[mi];
     M.group = h.group;
     M.material = h.material;
@@ -788,7 +791,7 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     M.root = (int32_t)nodes.size();
     M.tri_base = (int32_t)tris.size();
     M.ntris = (int32_t)h.ntris;
-    M.n_nodes = (int32_t)br.nodes.size();
+    M.n_nodes = (int32_t)wide.size();
     M.pad = 0;
     for (int a = 0; a < 3; a++) {
       M.lo[a] = br.lo[a];
@@ -797,9 +800,9 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     }
     M.scale = br.scale;
     int32_t node_base = (int32_t)nodes.size();
-    for (DNode N : br.nodes) {
-      if (N.c0 >= 0) N.c0 += node_base;
-      if (N.c1 >= 0) N.c1 += node_base;
+    for (DNode4 N : wide) {
+      for (int k = 0; k < 4; k++)
+        if (N.c[k] >= 0) N.c[k] += node_base;
       nodes.push_back(N);
     }
     for (int64_t k = 0; k < h.ntris; k++) {
@@ -881,7 +884,7 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   s->info.n_materials = (int64_t)mats.size();
   s->info.n_lights = (int64_t)s->lights.size();
   s->info.n_bvh_nodes = (int64_t)nodes.size();
-  s->info.node_bytes = (int32_t)sizeof(DNode);
+  s->info.node_bytes = (int32_t)sizeof(DNode4);
   s->info.tri_bytes = (int32_t)sizeof(DTri);
   s->info.device = device;
   s->info.bvh_builder = bvh_builder;

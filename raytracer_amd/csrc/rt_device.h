@@ -350,20 +350,19 @@ __device__ __forceinline__ bool box_may_hit(const DPrimBox& B, const BoxRay& r, 
 //     shadow distance or the trigger above) is converted with outward rounding.
 // A child is skipped only if its (enlarged) interval misses the (enlarged) query interval.
 struct NodeR {
-  uint32_t q[6];
-  int32_t c0, c1;
+  uint32_t q[12];
+  int32_t c[4];
 };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ NodeR node_from(u32x4 a, u32x4 b) {
+__device__ __forceinline__ NodeR load_node(const DNode4* p) {
+  const u32x4* w = reinterpret_cast<const u32x4*>(p);
+  const u32x4 a = w[0], b = w[1], d = w[2], e = w[3];
   NodeR r;
   r.q[0] = a.x; r.q[1] = a.y; r.q[2] = a.z; r.q[3] = a.w;
-  r.q[4] = b.x; r.q[5] = b.y;
-  r.c0 = (int32_t)b.z; r.c1 = (int32_t)b.w;
+  r.q[4] = b.x; r.q[5] = b.y; r.q[6] = b.z; r.q[7] = b.w;
+  r.q[8] = d.x; r.q[9] = d.y; r.q[10] = d.z; r.q[11] = d.w;
+  r.c[0] = (int32_t)e.x; r.c[1] = (int32_t)e.y; r.c[2] = (int32_t)e.z; r.c[3] = (int32_t)e.w;
   return r;
-}
-__device__ __forceinline__ NodeR load_node(const DNode* p) {
-  const u32x4* w = reinterpret_cast<const u32x4*>(p);
-  return node_from(w[0], w[1]);
 }
 // One triangle record as five 16-byte loads.  pin() makes the values live at one point, so
 // the compiler issues all the loads of a batch back to back and waits once, instead of
@@ -432,11 +431,11 @@ __device__ __forceinline__ float f32_down(double x) {  // largest float <= x
 }
 __device__ __forceinline__ float f32_up(double x) { return -f32_down(-x); }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct CullRay {
-  float a[3];   // cell / d of the culling ray
-  float cn[3];  // near-plane offsets, biased down
-  float cf[3];  // far-plane offsets, biased up
-  int sh[3];    // bit offset of the near plane's step in a node word: 16 if d < 0 else 0
+  float a[3];    // cell / d of the culling ray
+  f32x2 nf[3];   // .x: near-plane offset, biased down; .y: far-plane offset, biased up
+  int sh[3];     // rotation that brings the near plane's step to the low half of a node word: 16 if d < 0 else 0
   double t_base;
   bool miss;  // the ray does not touch the mesh's root box at all
 };
@@ -472,29 +471,34 @@ __device__ inline CullRay make_cull_ray(const DMesh& M, const Ray& lr, bool want
     c.sh[a] = (da < 0.0) ? 16 : 0;
     if (degenerate || !(fabs(oid) < 1e30) || !(fabs(inv) < 1e30)) {
       c.a[a] = 0.0f;  // no culling on this axis
-      c.cn[a] = -__builtin_huge_valf();
-      c.cf[a] = __builtin_huge_valf();
+      c.nf[a].x = -__builtin_huge_valf();
+      c.nf[a].y = __builtin_huge_valf();
     } else {
       c.a[a] = (float)(M.cell[a] * inv);
-      c.cn[a] = f32_down(oid - E);
-      c.cf[a] = f32_up(oid + E);
+      c.nf[a].x = f32_down(oid - E);
+      c.nf[a].y = f32_up(oid + E);
     }
   }
   return c;
 }
 
-// Enlarged parametric interval (in t - t_base) of one child box (three node words).
+// Enlarged parametric interval (in t - t_base) of one child box (three node words).  Per
+// axis: one rotation puts the near step in the low half, two half-word conversions, and one
+// packed fma for both planes (each half rounds exactly as a scalar fma would).
 __device__ __forceinline__ void slab32(const uint32_t* q, const CullRay& c, float& tn, float& tf) {
-  float n[3], f[3];
+  f32x2 t[3];
 #pragma unroll
   for (int a = 0; a < 3; a++) {
-    float qn = (float)__builtin_amdgcn_ubfe(q[a], (uint32_t)c.sh[a], 16u);
-    float qf = (float)__builtin_amdgcn_ubfe(q[a], (uint32_t)(16 - c.sh[a]), 16u);
-    n[a] = __fmaf_rn(qn, c.a[a], c.cn[a]);
-    f[a] = __fmaf_rn(qf, c.a[a], c.cf[a]);
+    const uint32_t r = __builtin_amdgcn_alignbit(q[a], q[a], (uint32_t)c.sh[a]);
+    f32x2 x, m;
+    x.x = (float)(r & 0xffffu);
+    x.y = (float)(r >> 16);
+    m.x = c.a[a];
+    m.y = c.a[a];
+    t[a] = __builtin_elementwise_fma(x, m, c.nf[a]);
   }
-  tn = fmaxf(fmaxf(n[0], n[1]), n[2]);
-  tf = fminf(fminf(f[0], f[1]), f[2]);
+  tn = fmaxf(fmaxf(t[0].x, t[1].x), t[2].x);
+  tf = fminf(fminf(t[0].y, t[1].y), t[2].y);
 }
 
 // true on the first active lane of the wave (statistics: counts an event once per wave)
@@ -515,20 +519,13 @@ struct HitRec {
 // (entry i of lane l at word i*64 + l: the lanes of a wave touch distinct banks whatever
 // their depths), deeper entries spill to a private array that well-built trees never reach.
 // The LDS pointer carries its address space so pushes and pops are plain ds_write/ds_read.
-constexpr int STACK_MAX = 64;
+constexpr int STACK_MAX = 96;
 #ifndef RT_LDS_STACK
 #define RT_LDS_STACK 24
 #endif
 constexpr int LDS_STACK = RT_LDS_STACK;
-// Build option RT_STAGE_TOP=1: the top of every mesh's tree (the builders put it first,
-// breadth first) is staged in LDS once per block, TOP_NODES 32-byte nodes shared evenly by
-// the scene's meshes (none when there are more than TOP_NODES / 8 meshes).  Off by default:
-// measured on MI355X it costs 6 % on the pawn frame and 20 % on the 1M-triangle scene — the
-// top of the tree is L1-resident anyway, and the extra branch splits the node fetch into an
-// LDS group and a global group of lanes.
-#ifndef RT_STAGE_TOP
-#define RT_STAGE_TOP 0
-#endif
+// The builders put the TOP_NODES nodes nearest each root first, breadth first, so the part
+// of a tree every ray walks sits in a few adjacent cache lines.
 constexpr int TOP_NODES = 128;
 constexpr int COOP_SLOTS = 64 * LEAF_MAX;
 typedef __attribute__((address_space(3))) int lds_int;
@@ -536,8 +533,6 @@ typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 struct TravStack {
   lds_int* lds;     // this lane's column
   int* spill;       // STACK_MAX - LDS_STACK private words
-  lds_u32x4* top;   // staged nodes: mesh m's node k at top[2 * (m * top_per_mesh + k)]
-  int top_per_mesh;
   lds_u32x4* rays;                                          // cooperative leaf tests: lane l's ray at rays[3*l..]
   __attribute__((address_space(3))) unsigned char* owners;  // ... and the slot -> lane table
   __device__ __forceinline__ void put(int i, int v) {
@@ -551,27 +546,12 @@ struct TravStack {
   }
 };
 // In a kernel of 64-thread blocks: RT_TRAV_STACK(st) declares the storage and the handle.
-__device__ __forceinline__ int stage_top_nodes(const DScene& S, lds_u32x4* top) {
-  if (!RT_STAGE_TOP) return 0;
-  int per = (S.n_meshes > 0 && S.n_meshes <= TOP_NODES / 8) ? TOP_NODES / S.n_meshes : 0;
-  const u32x4* src = reinterpret_cast<const u32x4*>(S.nodes);
-  for (int j = threadIdx.x; j < 2 * per * S.n_meshes; j += 64) {
-    int slot = j >> 1, m = slot / per, k = slot - m * per;
-    const DMesh& M = S.meshes[m];
-    if (k < M.n_nodes) top[j] = src[2 * (size_t)(M.root + k) + (j & 1)];
-  }
-  __syncthreads();
-  return per;
-}
 #define RT_TRAV_STACK(name, scene)                                              \
   __shared__ int name##_lds[rtd::LDS_STACK * 64];                               \
-  __shared__ rtd::u32x4 name##_top[RT_STAGE_TOP ? 2 * rtd::TOP_NODES : 1];      \
   int name##_spill[rtd::STACK_MAX - rtd::LDS_STACK];                            \
   rtd::TravStack name;                                                          \
   name.lds = (rtd::lds_int*)(name##_lds) + threadIdx.x;                         \
   name.spill = name##_spill;                                                    \
-  name.top = (rtd::lds_u32x4*)(name##_top);                                     \
-  name.top_per_mesh = rtd::stage_top_nodes(scene, name.top);                    \
   name.rays = nullptr;                                                          \
   name.owners = nullptr
 // ... plus the areas the cooperative leaf test shares between the lanes of the wave.
@@ -685,6 +665,50 @@ __device__ __forceinline__ bool test_leaf(uint32_t order_base, int tri_base, int
   return false;
 }
 
+// One step down a four-wide node: tests the four child boxes against the query interval
+// [qlo, qhi], returns the child to visit next (inner node index >= 0 or leaf code <= -2) and
+// pushes the other children that were hit so that the best of them is popped first.  With no
+// child hit the next entry comes off the stack (-1 when it is empty).
+//   Q_CLOSEST / Q_ANY: nearest entry point first; Q_PRED: the child reaching furthest up first.
+// The order only affects how soon the interval tightens, never the result: the comparisons
+// of accept_hit carry the leaf order.
+template <int MODE>
+__device__ __forceinline__ int node_step(const NodeR& N, const CullRay& c, float qlo, float qhi, int& sp,
+                                         TravStack& st) {
+  float key[4];
+  int code[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    float tn, tf;
+    slab32(N.q + 3 * k, c, tn, tf);
+    // an empty slot (code -1, inverted box) needs no test of its own: whatever its key, its
+    // code stays -1 and is neither pushed nor visited
+    const bool h = fmaxf(tn, qlo) <= fminf(tf, qhi);
+    key[k] = h ? ((MODE == Q_PRED) ? -tf : tn) : __builtin_huge_valf();
+    code[k] = h ? N.c[k] : -1;
+  }
+  // sorting network on (key, code): misses (key = +inf, code = -1) end up last
+#define RT_CSWAP(i, j)                                  \
+  {                                                     \
+    const bool sw = key[j] < key[i];                    \
+    const float ka = sw ? key[j] : key[i];              \
+    const float kb = sw ? key[i] : key[j];              \
+    const int ca = sw ? code[j] : code[i];              \
+    const int cb = sw ? code[i] : code[j];              \
+    key[i] = ka; key[j] = kb; code[i] = ca; code[j] = cb; \
+  }
+  RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+  // every hit child is pushed or returned whatever its position, so an unordered key
+  // (NaN from a degenerate axis) costs order, not correctness
+  // the scene commit refuses trees whose walk could need more than STACK_MAX entries
+  if (code[3] != -1) st.put(sp++, code[3]);
+  if (code[2] != -1) st.put(sp++, code[2]);
+  if (code[1] != -1) st.put(sp++, code[1]);
+  if (code[0] != -1) return code[0];
+  return sp ? st.get(--sp) : -1;
+}
+
 // Walks every mesh.  Returns true as soon as a Q_ANY query is satisfied.
 template <int MODE, bool STATS, bool FAST>
 __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q, Counters& cnt,
@@ -719,41 +743,14 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
     while (cur != -1) {
       const int alive = __popcll(__ballot(true));  // lanes of this wave still walking this mesh
       while (cur >= 0) {
-        NodeR N;
-        {
-          const int k = cur - M.root;
-          if (RT_STAGE_TOP && k < st.top_per_mesh) {
-            const lds_u32x4* w = st.top + 2 * (m * st.top_per_mesh + k);
-            N = node_from(w[0], w[1]);
-          } else {
-            N = load_node(S.nodes + cur);
-          }
-        }
+        const NodeR N = load_node(S.nodes + cur);
         if (STATS) {
           if (wave_leader()) cnt.node_wave_steps++;
           cnt.nodes_visited++;
           visited++;
           if (visited > cnt.max_nodes) cnt.max_nodes = visited;
         }
-        float tn0, tf0, tn1, tf1;
-        slab32(N.q, c, tn0, tf0);
-        slab32(N.q + 3, c, tn1, tf1);
-        bool h0 = fmaxf(tn0, qlo) <= fminf(tf0, qhi) && N.c0 != -1;
-        bool h1 = fmaxf(tn1, qlo) <= fminf(tf1, qhi) && N.c1 != -1;
-        if (h0 && h1) {
-          // Q_CLOSEST / Q_ANY: nearer child first; Q_PRED: the child reaching further up first
-          bool second_first = (MODE == Q_PRED) ? (tf1 > tf0) : (tn1 < tn0);
-          int near = second_first ? N.c1 : N.c0;
-          int far = second_first ? N.c0 : N.c1;
-          if (sp < STACK_MAX) st.put(sp++, far);
-          cur = near;
-        } else if (h0) {
-          cur = N.c0;
-        } else if (h1) {
-          cur = N.c1;
-        } else {
-          cur = sp ? st.get(--sp) : -1;
-        }
+        cur = node_step<MODE>(N, c, qlo, qhi, sp, st);
         // Once fewer than half of the wave's walking lanes are still descending, the rest
         // wait with a leaf: test those now and let the stragglers descend on their next turn.
         // Measured on MI355X (pawn 1080p): waiting for every lane 8.5 ms, this rule 7.05 ms;
@@ -798,7 +795,7 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
     c.miss = true;
     c.t_base = 0.0;
     for (int a = 0; a < 3; a++) {
-      c.a[a] = 0.f; c.cn[a] = 0.f; c.cf[a] = 0.f; c.sh[a] = 0;
+      c.a[a] = 0.f; c.nf[a].x = 0.f; c.nf[a].y = 0.f; c.sh[a] = 0;
     }
     const bool walking0 = enabled && !satisfied;
     if (walking0) {
@@ -844,24 +841,7 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
           visited++;
           if (visited > cnt.max_nodes) cnt.max_nodes = visited;
         }
-        float tn0, tf0, tn1, tf1;
-        slab32(N.q, c, tn0, tf0);
-        slab32(N.q + 3, c, tn1, tf1);
-        bool h0 = fmaxf(tn0, qlo) <= fminf(tf0, qhi) && N.c0 != -1;
-        bool h1 = fmaxf(tn1, qlo) <= fminf(tf1, qhi) && N.c1 != -1;
-        if (h0 && h1) {
-          bool second_first = (MODE == Q_PRED) ? (tf1 > tf0) : (tn1 < tn0);
-          int near = second_first ? N.c1 : N.c0;
-          int far = second_first ? N.c0 : N.c1;
-          if (sp < STACK_MAX) st.put(sp++, far);
-          cur = near;
-        } else if (h0) {
-          cur = N.c0;
-        } else if (h1) {
-          cur = N.c1;
-        } else {
-          cur = sp ? st.get(--sp) : -1;
-        }
+        cur = node_step<MODE>(N, c, qlo, qhi, sp, st);
         if (__popcll(__ballot(cur >= 0)) * 2 < alive) break;
       }
       // ---- shared leaf phase (all 64 lanes)
