@@ -203,39 +203,62 @@ void set_empty(rtd::DNode& N, int which) {
 }  // namespace
 
 namespace {
-int collapse_rec(const std::vector<rtd::DNode>& in, int i, std::vector<rtd::DNode4>& out, int self) {
-  // gather up to four (box words, code) slots: a leaf child stays, an inner child gives its two
-  uint32_t q[4][3];
-  int code[4];
+struct WideSlot {
+  uint32_t q[3];
+  int code;
+};
+double slot_area(const WideSlot& s, const double* cell) {
+  double e[3];
+  for (int a = 0; a < 3; a++) {
+    const double lo = (double)(s.q[a] & 0xffffu), hi = (double)(s.q[a] >> 16);
+    e[a] = (hi > lo ? hi - lo : 0.0) * cell[a];
+  }
+  return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+}
+int collapse_rec(const std::vector<rtd::DNode>& in, int i, std::vector<rtd::DNode4>& out, int self,
+                 const double* cell) {
+  // Start from the two children of the binary node and, while a slot is free, open the inner
+  // child with the largest surface (the one a ray is most likely to enter anyway).
+  WideSlot slot[4];
   int n = 0;
-  const rtd::DNode& N = in[i];
-  const int cs[2] = {N.c0, N.c1};
-  for (int w = 0; w < 2; w++) {
-    if (cs[w] == -1) continue;
-    if (cs[w] <= -2) {
-      for (int a = 0; a < 3; a++) q[n][a] = N.q[3 * w + a];
-      code[n++] = cs[w];
-    } else {
-      const rtd::DNode& C = in[cs[w]];
-      const int gs[2] = {C.c0, C.c1};
-      for (int v = 0; v < 2; v++) {
-        if (gs[v] == -1) continue;
-        for (int a = 0; a < 3; a++) q[n][a] = C.q[3 * v + a];
-        code[n++] = gs[v];
-      }
+  auto add_children = [&](const rtd::DNode& N) {
+    const int cs[2] = {N.c0, N.c1};
+    for (int w = 0; w < 2; w++) {
+      if (cs[w] == -1) continue;
+      for (int a = 0; a < 3; a++) slot[n].q[a] = N.q[3 * w + a];
+      slot[n++].code = cs[w];
     }
+  };
+  add_children(in[i]);
+  while (n < 4) {
+    int best = -1;
+    double best_area = -1.0;
+    for (int k = 0; k < n; k++)
+      if (slot[k].code >= 0) {
+        const double area = slot_area(slot[k], cell);
+        if (area > best_area) {
+          best_area = area;
+          best = k;
+        }
+      }
+    if (best < 0) break;
+    const rtd::DNode& C = in[slot[best].code];
+    const int kids = (C.c0 != -1) + (C.c1 != -1);
+    if (n - 1 + kids > 4) break;
+    slot[best] = slot[--n];
+    add_children(C);
   }
   int depth = 1;
   for (int k = 0; k < 4; k++) {
     if (k < n) {
-      for (int a = 0; a < 3; a++) out[self].q[3 * k + a] = q[k][a];
-      if (code[k] >= 0) {
+      for (int a = 0; a < 3; a++) out[self].q[3 * k + a] = slot[k].q[a];
+      if (slot[k].code >= 0) {
         const int child = (int)out.size();
         out.emplace_back();
         out[self].c[k] = child;
-        depth = std::max(depth, 1 + collapse_rec(in, code[k], out, child));
+        depth = std::max(depth, 1 + collapse_rec(in, slot[k].code, out, child, cell));
       } else {
-        out[self].c[k] = code[k];
+        out[self].c[k] = slot[k].code;
       }
     } else {
       for (int a = 0; a < 3; a++) out[self].q[3 * k + a] = 0xffffu;  // lo = 65535, hi = 0
@@ -246,7 +269,7 @@ int collapse_rec(const std::vector<rtd::DNode>& in, int i, std::vector<rtd::DNod
 }
 }  // namespace
 
-int collapse_to_wide(const std::vector<rtd::DNode>& nodes, std::vector<rtd::DNode4>& out) {
+int collapse_to_wide(const std::vector<rtd::DNode>& nodes, const double* cell, std::vector<rtd::DNode4>& out) {
   out.clear();
   out.reserve(nodes.size() / 2 + 2);
   out.emplace_back();
@@ -257,7 +280,7 @@ int collapse_to_wide(const std::vector<rtd::DNode>& nodes, std::vector<rtd::DNod
     }
     return 1;
   }
-  return collapse_rec(nodes, 0, out, 0);
+  return collapse_rec(nodes, 0, out, 0, cell);
 }
 
 void reorder_top_breadth_first(std::vector<rtd::DNode4>& nodes, int top) {

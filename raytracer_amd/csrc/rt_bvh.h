@@ -30,9 +30,10 @@ void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, 
 int build_lbvh_device(const double* p1, const double* p2, const double* p3, int64_t n, int max_leaf,
                       BuildResult& out, std::string& err);
 
-// Folds a binary tree (nodes[0] = root) into four-wide nodes: every inner child of a binary
-// node is replaced by its own two children.  Returns the depth of the wide tree (root = 1).
-int collapse_to_wide(const std::vector<rtd::DNode>& nodes, std::vector<rtd::DNode4>& out);
+// Folds a binary tree (nodes[0] = root) into four-wide nodes: the inner children of a binary
+// node are opened, largest surface first (cell = the mesh's grid steps), until four slots are
+// taken.  Returns the depth of the wide tree (root = 1).
+int collapse_to_wide(const std::vector<rtd::DNode>& nodes, const double* cell, std::vector<rtd::DNode4>& out);
 
 // Moves the top of the tree to the front of `nodes`: the first `top` entries become the
 // nodes nearest the root in breadth-first order (the root stays entry 0); the others keep

@@ -780,7 +780,7 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     }
     // the kernels walk four-wide nodes; a step leaves up to three children on the stack
     std::vector<DNode4> wide;
-    const int wide_depth = rtb::collapse_to_wide(br.nodes, wide);
+    const int wide_depth = rtb::collapse_to_wide(br.nodes, br.cell, wide);
     if (3 * wide_depth + 2 >= STACK_MAX)
       return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     rtb::reorder_top_breadth_first(wide, TOP_NODES);
@@ -1047,6 +1047,8 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
   if (!planned) {
     s->wf_plan_key = key;
     s->wf_plan_levels = levels;
+    if (getenv("RT_TRACE_LEVELS"))  // queue length of every level of a newly planned frame
+      for (int l = 0; l < levels; l++) fprintf(stderr, "rt: level %d: %lld tasks\n", l, level_n[l]);
   }
   for (int l = levels - 1 - (direct_last ? 1 : 0); l >= 0; l--) {
     long long m = level_n[l];

@@ -447,8 +447,10 @@ __device__ inline CullRay make_cull_ray(const DMesh& M, const Ray& lr, bool want
   const double d[3] = {lr.d.x, lr.d.y, lr.d.z};
   // where the true ray crosses the root box (f64; NaN from 0*inf is ignored by fmin/fmax)
   double tin = -RT_INF, tout = RT_INF;
+  double invd[3];
   for (int a = 0; a < 3; a++) {
     double inv = 1.0 / d[a];
+    invd[a] = inv;
     double t0 = (M.lo[a] - o[a]) * inv, t1 = (M.hi[a] - o[a]) * inv;
     tin = fmax(tin, fmin(t0, t1));
     tout = fmin(tout, fmax(t0, t1));
@@ -464,8 +466,11 @@ __device__ inline CullRay make_cull_ray(const DMesh& M, const Ray& lr, bool want
     double oa = o[a] + d[a] * tb;  // re-based origin
     double da = d[a];
     double dmin = dmax * 1e-10;
-    if (!(fabs(da) >= dmin)) da = (da < 0.0) ? -dmin : dmin;
-    double inv = 1.0 / da;
+    double inv = invd[a];
+    if (!(fabs(da) >= dmin)) {  // rare: only then is a second division needed
+      da = (da < 0.0) ? -dmin : dmin;
+      inv = 1.0 / da;
+    }
     double oid = (M.lo[a] - oa) * inv;
     double E = (6.0 * 5.9604644775390625e-08) * (M.scale + fabs(oa)) * fabs(inv);
     c.sh[a] = (da < 0.0) ? 16 : 0;
@@ -499,6 +504,16 @@ __device__ __forceinline__ void slab32(const uint32_t* q, const CullRay& c, floa
   }
   tn = fmaxf(fmaxf(t[0].x, t[1].x), t[2].x);
   tf = fminf(fminf(t[0].y, t[1].y), t[2].y);
+}
+
+// Orders this lane's LDS accesses against those of the other lanes of its wave.  A wave's LDS
+// instructions already execute in order; this tells the compiler, which reasons per lane and
+// may otherwise forward a lane's own earlier store to its load of a slot that another lane
+// has written in between.  Generates no instructions.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // true on the first active lane of the wave (statistics: counts an event once per wave)
@@ -697,7 +712,11 @@ __device__ __forceinline__ int node_step(const NodeR& N, const CullRay& c, float
     const int cb = sw ? code[i] : code[j];              \
     key[i] = ka; key[j] = kb; code[i] = ca; code[j] = cb; \
   }
-  RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+  // Shadow queries stop at the first hit wherever it is: visiting order buys them little, so
+  // they take the hit children as they come (measured: 2 % of the frame on MI355X).
+  if (MODE != Q_ANY) {
+    RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+  }
 #undef RT_CSWAP
   // every hit child is pushed or returned whatever its position, so an unordered key
   // (NaN from a degenerate axis) costs order, not correctness
@@ -819,6 +838,7 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
       st.rays[3 * lane + 0] = w0;
       st.rays[3 * lane + 1] = w1;
       st.rays[3 * lane + 2] = w2;
+      wave_lds_fence();
     }
     float qlo = 0.f, qhi = 0.f;
     if (MODE == Q_PRED) {
@@ -867,6 +887,7 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
         for (int j = j0; j < j0 + 4; j++)
           if (j < lcount) st.owners[off + j] = (unsigned char)lane;
       }
+      wave_lds_fence();
       for (int base = 0; base < total; base += 64) {  // wave-uniform
         const int s = base + lane;
         const bool work = s < total;
