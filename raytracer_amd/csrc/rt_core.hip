@@ -82,10 +82,23 @@ struct rt_scene {
   // RT_SHARE_LEAVES=0 selects the per-lane leaf tests instead.
   std::vector<std::pair<uint64_t, int>> auto_choice;  // frame key -> pipeline picked by RT_PIPELINE_AUTO
   bool share_leaves = true;
-  uint64_t wf_plan_key = 0;
-  int wf_plan_levels = 0;
-  long long wf_plan_n[MAX_DEPTH + 1] = {}, wf_plan_front[MAX_DEPTH + 1] = {};
+  // Queue lengths of frames rendered with host read-backs: the same frame (camera, shard,
+  // depth, mode) is then issued again without any synchronisation.
+  struct WfPlan {
+    uint64_t key = 0;
+    int levels = 0;
+    long long n[MAX_DEPTH + 1] = {}, front[MAX_DEPTH + 1] = {};
+  };
+  std::vector<WfPlan> wf_plans;  // most recent last, at most WF_MAX_PLANS
+  // A wavefront frame is rendered as frame_split interleaved tile shards on streams of the
+  // scene's own, forked from and joined to the caller's stream, so that the thin tail of one
+  // shard's level runs under another shard's work (RT_FRAME_SPLIT, 1 = off).
+  int frame_split = 1;
+  std::vector<hipStream_t> split_streams;
+  std::vector<hipEvent_t> split_joined;
+  hipEvent_t split_fork = nullptr;
 };
+static constexpr size_t WF_MAX_PLANS = 64;
 
 static bool affine_rows(const double* m16, double* out12, std::string& why) {
   if (!(m16[12] == 0.0 && m16[13] == 0.0 && m16[14] == 0.0 && m16[15] == 1.0)) {
@@ -188,7 +201,10 @@ static DPrimBox world_box_of(const rt_scene* s, const rt_primitive& P) {
 // 64-thread block (one wave) shades one 8x8 pixel patch of it.
 struct PixelMap {
   int hsize, vsize, tiles_x;
-  int tile_first, tile_step;
+  int tile_first, tile_step;  // this launch renders tiles tile_first, tile_first + tile_step, ...
+  // Where local tile k of this launch goes: into the row-major image, or to slot
+  // k * out_k_mul + out_k_add of a compact buffer of whole tiles (a shard's output).
+  int out_row_major, out_k_mul, out_k_add;
 };
 
 __device__ __forceinline__ bool lane_pixel(const PixelMap& pm, int& px, int& py, long long& out_index) {
@@ -203,10 +219,10 @@ __device__ __forceinline__ bool lane_pixel(const PixelMap& pm, int& px, int& py,
   int iy = (patch / (RT_TILE / 8)) * 8 + (lane >> 3);
   px = tx * RT_TILE + ix;
   py = ty * RT_TILE + iy;
-  if (pm.tile_step == 1)
+  if (pm.out_row_major)
     out_index = (long long)py * pm.hsize + px;
   else
-    out_index = k * (RT_TILE * RT_TILE) + iy * RT_TILE + ix;
+    out_index = (k * pm.out_k_mul + pm.out_k_add) * (RT_TILE * RT_TILE) + iy * RT_TILE + ix;
   return px < pm.hsize && py < pm.vsize;
 }
 
@@ -582,6 +598,9 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->d_out_u8) (void)hipFree(s->d_out_u8);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->split_fork) (void)hipEventDestroy(s->split_fork);
+    for (hipEvent_t e : s->split_joined) (void)hipEventDestroy(e);
+    for (hipStream_t q : s->split_streams) (void)hipStreamDestroy(q);
     for (rt_scene::WfState* w : s->wf_states) {
       for (int l = 0; l <= MAX_DEPTH; l++) {
         if (w->wf_tasks[l]) (void)hipFree(w->wf_tasks[l]);
@@ -865,6 +884,7 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   if ((rc = upload(s, s->lights, &s->d.lights))) return rc;
   s->share_leaves = true;
   if (const char* e = getenv("RT_SHARE_LEAVES")) s->share_leaves = atoi(e) != 0;
+  if (const char* e = getenv("RT_FRAME_SPLIT")) s->frame_split = std::min(std::max(atoi(e), 1), 8);
   s->d.n_groups = (int32_t)groups.size();
   s->d.n_prims = (int32_t)prims.size();
   s->d.n_meshes = (int32_t)meshes.size();
@@ -921,6 +941,20 @@ static int camera_to_device(const rt_camera* c, DCamera& d) {
   return RT_OK;
 }
 
+// A whole call's pixel map: all the image row-major, or a shard into its compact tile buffer.
+static PixelMap pixel_map(const rt_camera* cam, int tile_first, int tile_step) {
+  PixelMap pm;
+  pm.hsize = cam->hsize;
+  pm.vsize = cam->vsize;
+  pm.tiles_x = (cam->hsize + RT_TILE - 1) / RT_TILE;
+  pm.tile_first = tile_first;
+  pm.tile_step = tile_step;
+  pm.out_row_major = (tile_step == 1) ? 1 : 0;
+  pm.out_k_mul = 1;
+  pm.out_k_add = 0;
+  return pm;
+}
+
 static int wf_ensure(void** p, size_t* cap, size_t need, size_t elem) {
   if (need <= *cap) return RT_OK;
   if (*p) HIP_TRY(hipFree(*p));
@@ -956,12 +990,19 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
                             int depth, double* d_f64, uint8_t* d_u8, hipStream_t st, bool stats,
                             bool fast) {
   const uint64_t key = frame_key(dc, pm, depth, fast);
-  const bool planned = (key == s->wf_plan_key);
+  rt_scene::WfPlan plan;  // a copy: the list may be reordered below
+  bool planned = false;
+  for (const rt_scene::WfPlan& c : s->wf_plans)
+    if (c.key == key) {
+      plan = c;
+      planned = true;
+    }
+  if (!planned) plan.key = key;
   rt_scene::WfState* w = nullptr;
   for (rt_scene::WfState* c : s->wf_states)
     if (c->stream == st) w = c;
   if (!w) {
-    constexpr size_t WF_MAX_STREAMS = 4;
+    constexpr size_t WF_MAX_STREAMS = 8;
     if (s->wf_states.size() < WF_MAX_STREAMS) {
       w = new rt_scene::WfState;
       w->stream = st;
@@ -1029,24 +1070,25 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     levels = l + 1;
     if (!spawn) break;
     if (planned) {
-      if (l + 1 >= s->wf_plan_levels) break;
-      n = s->wf_plan_n[l + 1];
-      n_front = s->wf_plan_front[l + 1];
+      if (l + 1 >= plan.levels) break;
+      n = plan.n[l + 1];
+      n_front = plan.front[l + 1];
     } else {
       HIP_TRY(hipMemcpyAsync(w->wf_counts_host + 2 * (l + 1), cnt_next, 2 * sizeof(unsigned int),
                              hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       n_front = w->wf_counts_host[2 * (l + 1)];
       n = n_front + w->wf_counts_host[2 * (l + 1) + 1];
-      s->wf_plan_n[l + 1] = n;
-      s->wf_plan_front[l + 1] = n_front;
+      plan.n[l + 1] = n;
+      plan.front[l + 1] = n_front;
     }
     cap_in = cap;
     if (n == 0) break;
   }
   if (!planned) {
-    s->wf_plan_key = key;
-    s->wf_plan_levels = levels;
+    plan.levels = levels;
+    if (s->wf_plans.size() >= WF_MAX_PLANS) s->wf_plans.erase(s->wf_plans.begin());
+    s->wf_plans.push_back(plan);
     if (getenv("RT_TRACE_LEVELS"))  // queue length of every level of a newly planned frame
       for (int l = 0; l < levels; l++) fprintf(stderr, "rt: level %d: %lld tasks\n", l, level_n[l]);
   }
@@ -1086,19 +1128,44 @@ static int render_device_fixed(rt_scene* s, const rt_camera* cam, int depth, int
   if (ntiles < 0) return fail(RT_ERR_ARG, "bad tile shard");
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   HIP_TRY(hipSetDevice(s->device));
-  PixelMap pm;
-  pm.hsize = cam->hsize;
-  pm.vsize = cam->vsize;
-  pm.tiles_x = (cam->hsize + RT_TILE - 1) / RT_TILE;
-  pm.tile_first = tile_first;
-  pm.tile_step = tile_step;
+  const PixelMap pm = pixel_map(cam, tile_first, tile_step);
   if (want_stats) HIP_TRY(hipMemsetAsync(s->d_counters, 0, (N_COUNTERS + 1) * sizeof(unsigned long long), st));
   HIP_TRY(hipEventRecord(s->ev0, st));
   s->launches = 0;
   if (ntiles > 0 && pipeline == RT_PIPELINE_WAVEFRONT && depth > 0) {
-    rc = render_wavefront(s, dc, pm, ntiles, depth, d_rgb_f64, d_rgb_u8, st, want_stats != 0,
-                          mode == RT_MODE_F32_FAST);
-    if (rc) return rc;
+    // interleaved sub-shards of this call's tiles, each a wavefront frame of its own
+    int split = s->frame_split;
+    if (ntiles < 64 * (int64_t)split) split = 1;  // too small to be worth the extra launches
+    if (split > 1) {
+      while ((int)s->split_streams.size() < split - 1) {
+        hipStream_t q = nullptr;
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+        s->split_streams.push_back(q);
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s->split_joined.push_back(e);
+      }
+      if (!s->split_fork) HIP_TRY(hipEventCreateWithFlags(&s->split_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(s->split_fork, st));
+    }
+    for (int i = 0; i < split; i++) {
+      PixelMap sub = pm;
+      sub.tile_first = tile_first + i * tile_step;
+      sub.tile_step = tile_step * split;
+      sub.out_k_mul = split;
+      sub.out_k_add = i;
+      const int64_t sub_tiles = rt_shard_tiles(cam->hsize, cam->vsize, sub.tile_first, sub.tile_step);
+      if (sub_tiles <= 0) continue;
+      hipStream_t q = (i == 0) ? st : s->split_streams[i - 1];
+      if (i > 0) HIP_TRY(hipStreamWaitEvent(q, s->split_fork, 0));
+      rc = render_wavefront(s, dc, sub, sub_tiles, depth, d_rgb_f64, d_rgb_u8, q, want_stats != 0,
+                            mode == RT_MODE_F32_FAST);
+      if (rc) return rc;
+      if (i > 0) {
+        HIP_TRY(hipEventRecord(s->split_joined[i - 1], q));
+        HIP_TRY(hipStreamWaitEvent(st, s->split_joined[i - 1], 0));
+      }
+    }
   } else if (ntiles > 0) {
     constexpr int PATCHES = (RT_TILE / 8) * (RT_TILE / 8);
     dim3 grid((unsigned)(ntiles * PATCHES)), block(64);
@@ -1133,12 +1200,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, int depth, int mode, int
   DCamera dc;
   int rc = camera_to_device(cam, dc);
   if (rc) return rc;
-  PixelMap pm;
-  pm.hsize = cam->hsize;
-  pm.vsize = cam->vsize;
-  pm.tiles_x = (cam->hsize + RT_TILE - 1) / RT_TILE;
-  pm.tile_first = tile_first;
-  pm.tile_step = tile_step;
+  const PixelMap pm = pixel_map(cam, tile_first, tile_step);
   const uint64_t key = frame_key(dc, pm, depth, false);
   for (const auto& kv : s->auto_choice)
     if (kv.first == key)

@@ -456,3 +456,29 @@ def test_tile_shards_stitch_to_the_full_image(rt, nshards):
     rt.detile_u8(tiles.data_ptr(), nshards, per, hs, vs, img.data_ptr(), stream)
     torch.cuda.synchronize()
     assert np.array_equal(img.cpu().numpy(), full)
+
+
+@pytest.mark.parametrize("split", [2, 3])
+def test_frame_split_over_internal_streams(rt, split, monkeypatch):
+    """RT_FRAME_SPLIT renders a wavefront frame as interleaved sub-shards on the scene's own
+    streams: the full image and a shard's compact tile buffer must come out bit-identical."""
+    import torch
+    name, hs, vs = "pawn", 1000, 562  # ragged; 32 x 18 tiles
+    ref = rt.World.example(name, hs, vs).commit()
+    full, _, _ = ref.render(pipeline=rt.PIPELINE_WAVEFRONT)
+    monkeypatch.setenv("RT_FRAME_SPLIT", str(split))
+    w = rt.World.example(name, hs, vs).commit()
+    for _ in range(2):  # the second frame is issued from the remembered queue lengths
+        got, _, _ = w.render(pipeline=rt.PIPELINE_WAVEFRONT)
+        assert np.array_equal(got, full)
+    nshards = 2
+    per = max(rt.shard_tiles(hs, vs, s, nshards) for s in range(nshards))
+    tiles = torch.zeros((nshards, per * rt.TILE * rt.TILE * 3), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for s in range(nshards):
+        w.render_device(d_u8=tiles[s].data_ptr(), stream=stream, tile_first=s, tile_step=nshards,
+                        pipeline=rt.PIPELINE_WAVEFRONT)
+    img = torch.zeros((vs, hs, 3), dtype=torch.uint8, device="cuda")
+    rt.detile_u8(tiles.data_ptr(), nshards, per, hs, vs, img.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(img.cpu().numpy(), full)
