@@ -37,10 +37,11 @@ PEAK_F64_TFLOPS = 78.6
 def algorithmic_work(st, node_bytes):
     """Per-frame algorithmic bytes and flops from the traversal counters:
     bytes = node_bytes*nodes + 72*tri_tests + 72*shaded mesh hits (normals);
-    flops = 36*nodes (two 18-flop box tests) + 46*tri_tests + 56*instance entries
-            + 30*primitive tests + 200*shade calls."""
+    flops = 18*children*nodes (one 18-flop box test per child of a node: 16 bytes of a node
+            hold one child) + 46*tri_tests + 56*instance entries + 30*primitive tests
+            + 200*shade calls."""
     b = node_bytes * st["nodes_visited"] + 72 * st["tri_tests"] + 72 * st["shade_calls"]
-    f = (36 * st["nodes_visited"] + 46 * st["tri_tests"] + 56 * st["inst_entries"] +
+    f = (18 * (node_bytes // 16) * st["nodes_visited"] + 46 * st["tri_tests"] + 56 * st["inst_entries"] +
          30 * st["prim_tests"] + 200 * st["shade_calls"])
     return b, f
 
