@@ -516,6 +516,19 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave, all of which must be active: four shifted
+// adds inside each row of 16 lanes, then the row totals carried over with the two row
+// broadcasts (six cross-lane VALU operations, no LDS).
+__device__ __forceinline__ int wave_inclusive_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1, 0 shifted in
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // true on the first active lane of the wave (statistics: counts an event once per wave)
 __device__ __forceinline__ bool wave_leader() {
   unsigned long long m = __ballot(1);
@@ -869,16 +882,10 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
       const int code = has_leaf ? -2 - cur : 0;
       const int lfirst = code >> LEAF_BITS;
       const int lcount = has_leaf ? (code & LEAF_MAX) : 0;
-      // prefix sum of the counts (LEAF_BITS-bit numbers) from one ballot per bit: no
-      // cross-lane data movement
-      const unsigned long long below = (1ull << lane) - 1ull;
-      int off = 0, total = 0;
-#pragma unroll
-      for (int b = 0; b < LEAF_BITS; b++) {
-        const unsigned long long bal = __ballot((lcount >> b) & 1);
-        off += __popcll(bal & below) << b;
-        total += __popcll(bal) << b;
-      }
+      // prefix sum of the counts over the wave
+      const int upto = wave_inclusive_sum(lcount);
+      const int off = upto - lcount;
+      const int total = __builtin_amdgcn_readlane(upto, 63);
       bool hit_any = false;
       // predicated stores, four at a time under one wave-uniform test
       for (int j0 = 0; j0 < LEAF_MAX; j0 += 4) {
