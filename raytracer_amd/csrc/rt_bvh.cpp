@@ -248,7 +248,9 @@ int collapse_rec(const std::vector<rtd::DNode>& in, int i, std::vector<rtd::DNod
     slot[best] = slot[--n];
     add_children(C);
   }
-  int depth = 1;
+  // stack entries a walk of this subtree can hold at once: while one child is walked, the
+  // other n - 1 may all be waiting on the stack
+  int below = 0;
   for (int k = 0; k < 4; k++) {
     if (k < n) {
       for (int a = 0; a < 3; a++) out[self].q[3 * k + a] = slot[k].q[a];
@@ -256,7 +258,7 @@ int collapse_rec(const std::vector<rtd::DNode>& in, int i, std::vector<rtd::DNod
         const int child = (int)out.size();
         out.emplace_back();
         out[self].c[k] = child;
-        depth = std::max(depth, 1 + collapse_rec(in, slot[k].code, out, child, cell));
+        below = std::max(below, collapse_rec(in, slot[k].code, out, child, cell));
       } else {
         out[self].c[k] = slot[k].code;
       }
@@ -265,7 +267,7 @@ int collapse_rec(const std::vector<rtd::DNode>& in, int i, std::vector<rtd::DNod
       out[self].c[k] = -1;
     }
   }
-  return depth;
+  return std::max(n - 1, 0) + below;
 }
 }  // namespace
 
@@ -278,7 +280,7 @@ int collapse_to_wide(const std::vector<rtd::DNode>& nodes, const double* cell, s
       for (int a = 0; a < 3; a++) out[0].q[3 * k + a] = 0xffffu;
       out[0].c[k] = -1;
     }
-    return 1;
+    return 0;
   }
   return collapse_rec(nodes, 0, out, 0, cell);
 }

@@ -32,7 +32,7 @@ int build_lbvh_device(const double* p1, const double* p2, const double* p3, int6
 
 // Folds a binary tree (nodes[0] = root) into four-wide nodes: the inner children of a binary
 // node are opened, largest surface first (cell = the mesh's grid steps), until four slots are
-// taken.  Returns the depth of the wide tree (root = 1).
+// taken.  Returns the largest number of stack entries a walk of the wide tree can hold.
 int collapse_to_wide(const std::vector<rtd::DNode>& nodes, const double* cell, std::vector<rtd::DNode4>& out);
 
 // Moves the top of the tree to the front of `nodes`: the first `top` entries become the

@@ -799,8 +799,8 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     }
     // the kernels walk four-wide nodes; a step leaves up to three children on the stack
     std::vector<DNode4> wide;
-    const int wide_depth = rtb::collapse_to_wide(br.nodes, br.cell, wide);
-    if (3 * wide_depth + 2 >= STACK_MAX)
+    const int stack_need = rtb::collapse_to_wide(br.nodes, br.cell, wide);
+    if (stack_need > STACK_MAX)
       return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     rtb::reorder_top_breadth_first(wide, TOP_NODES);
     DMesh& M = meshes[mi];

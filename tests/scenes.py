@@ -129,3 +129,26 @@ def tie_scene(T, M, X):
     T.add_shape(PLANE, X.translation(0.0, -1.0, 0.0), M(pattern=CHECKERED, a=(0, 0, 0), b=(1, 1, 1)))
     T.set_camera(80, 48, math.pi / 3.0,
                  X.view_transform((0.0, 1.0, -7.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)))
+
+
+def deep_tree_scene(T, M, X, n_same=600, n_line=400):
+    """Meshes that drive a BVH builder into its worst shapes: many copies of one triangle
+    (no split separates them: the SAH builder falls back to median splits, Morton codes are
+    all equal) and triangles whose sizes and gaps shrink geometrically along a line (every
+    split peels one triangle off: a tree as deep as the builder allows)."""
+    T.add_light((1.0, 1.0, 1.0), (-6.0, 8.0, -10.0))
+    T.add_shape(PLANE, X.translation(0.0, -1.5, 0.0), M(pattern=CHECKERED, a=(0.9, 0.9, 0.9), b=(0.2, 0.2, 0.2)))
+    g = T.add_group(X.translation(-1.5, 0.0, 0.0), M(a=(0.8, 0.3, 0.2), transparency=0.5, refractive_index=1.3))
+    tri = np.array([-1.0, -1.0, 0.0, 1.0, -1.0, 0.0, 0.0, 1.0, 0.0])
+    for i in range(n_same):
+        T.add_triangle(tri, None, parent=g)
+    h = T.add_group(X.translation(0.5, -1.0, 0.0), M(a=(0.2, 0.5, 0.9), reflective=0.3))
+    x = 0.0
+    size = 1.0
+    for i in range(n_line):
+        p = np.array([x, 0.0, 0.0, x + size, 0.0, 0.0, x, 2.0 * size + 0.05, 0.3])
+        T.add_triangle(p, None, parent=h)
+        x += 1.2 * size
+        size *= 0.93
+    T.set_camera(120, 80, math.pi / 3.0,
+                 X.view_transform((0.5, 1.0, -7.0), (0.5, 0.0, 0.0), (0.0, 1.0, 0.0)))

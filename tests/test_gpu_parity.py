@@ -261,6 +261,17 @@ def test_mesh_sizes_around_the_leaf_limits(rt, O, n_tris, bvh_builder):
     assert np.abs(f64 - of64).max() <= 1e-11
 
 
+@pytest.mark.parametrize("bvh_builder", [0, 1])
+def test_worst_case_trees(rt, O, bvh_builder):
+    """Hundreds of coincident triangles and a geometric row of shrinking ones: the deepest
+    trees either builder makes must fit the traversal stack and render the reference's bits."""
+    w, s = build_both(rt, O, scenes.deep_tree_scene, bvh_builder=bvh_builder)
+    u8, f64, _ = w.render(want_f64=True)
+    of64, ou8, _ = s.render()
+    assert np.array_equal(u8, ou8)
+    assert np.abs(f64 - of64).max() <= 1e-11
+
+
 def test_equal_t_ties_resolved_by_leaf_order(rt, O):
     w, s = build_both(rt, O, scenes.tie_scene)
     u8, f64, _ = w.render(want_f64=True)
