@@ -446,6 +446,19 @@ __device__ __forceinline__ void emit_result(const ShadeOut& so, const C3& surfac
   }
 }
 
+#ifdef RT_SECTION_TIMES
+// Diagnostic build: wave cycles per section of k_wf_level, summed over all waves.
+__device__ unsigned long long g_section_cycles[8];
+#define RT_SECTION(k)                                                              \
+  do {                                                                             \
+    const unsigned long long now_ = __builtin_readcyclecounter();                  \
+    if (threadIdx.x == 0) atomicAdd(&g_section_cycles[k], now_ - section_t_);      \
+    section_t_ = now_;                                                             \
+  } while (0)
+#else
+#define RT_SECTION(k) do { } while (0)
+#endif
+
 template <bool STATS, bool PRIMARY, bool FAST, bool COOP>
 __global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
 k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n, long long n_front,
@@ -453,6 +466,9 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
            unsigned int* next_count, unsigned int next_cap, int spawn, unsigned long long* counters) {
   static_assert(WF_BLOCK == 64, "the traversal stack is laid out for 64-lane blocks");
   RT_TRAV_STACK_COOP(st, S);
+#ifdef RT_SECTION_TIMES
+  unsigned long long section_t_ = __builtin_readcyclecounter();
+#endif
   Counters cnt{};
   long long i = (long long)blockIdx.x * WF_BLOCK + threadIdx.x;
   bool active;
@@ -491,7 +507,9 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
     // Every lane of the wave goes through the three queries together (the lanes share the
     // triangle tests of each other's leaves); `active`, `hit` and `need` say who has one.
     HitRec h;
+    RT_SECTION(0);
     const bool hit = trace_closest_coop<STATS, FAST>(S, ray, active, h, cnt, st);
+    RT_SECTION(1);
     Prep pr;
     pr.mat_index = 0;
     C3 surface = {0.0, 0.0, 0.0};
@@ -509,7 +527,9 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
         shadow_ray(L, pr.over, sr, distance);
         if (STATS) cnt.rays_shadow++;
       }
+      RT_SECTION(2);
       const bool shadow = trace_any_coop<STATS, FAST>(S, sr, distance, hit, cnt, st);
+      RT_SECTION(3);
       if (hit) add_light(S.mats[pr.mat_index], L, pc, sr.d, pr.normal, vneg(ray.d), shadow, surface);
     }
     const bool need = hit && needs_n1_n2(S.mats[pr.mat_index]);
@@ -520,9 +540,11 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
       K = trigger_key(S, ray, h);
     }
     bool tf = false;
+    RT_SECTION(2);
     if (S.n_meshes > 0)
       tf = tri_predecessor_coop<STATS, FAST>(S, ray, predecessor_bound(K), h.prim >= 0 ? -1 : h.tri, need, tb,
                                              tm, cnt, st);
+    RT_SECTION(4);
     if (hit) {
       const DMaterial& M = S.mats[pr.mat_index];
       double n1 = 1.0, n2 = 1.0;
@@ -548,6 +570,7 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
   } else if (PRIMARY || active) {
     nodes[i] = nd;
   }
+  RT_SECTION(5);
   flush_counters<STATS>(cnt, counters);
 }
 
@@ -576,6 +599,16 @@ static int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
 
 // ---------------------------------------------------------------------------------------
 extern "C" {
+#ifdef RT_SECTION_TIMES
+int rt_debug_section_cycles(unsigned long long* out8, int reset) {
+  if (out8) HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_section_cycles), 8 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[8] = {};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_section_cycles), z, sizeof z));
+  }
+  return RT_OK;
+}
+#endif
 
 const char* rt_last_error(void) { return g_err.c_str(); }
 

@@ -1,0 +1,20 @@
+"""Where a wave of k_wf_level spends its cycles (needs a build with -DRT_SECTION_TIMES:
+bash scripts/build_variant.sh sect -DRT_SECTION_TIMES; RT_LIB=variants/sect.so python scripts/section_times.py)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import raytracer_amd as rt
+name, hs, vs = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else ("pawn", 1920, 1080)
+w = rt.World.example(name, hs, vs).commit()
+w.render(); w.render()
+L = w.L
+out = (C.c_ulonglong * 8)()
+L.rt_debug_section_cycles(None, 1)
+w.render()
+torch.cuda.synchronize()
+L.rt_debug_section_cycles(out, 0)
+names = ["task load / ray generation", "closest-hit traversal", "prepare, pattern, lighting", "shadow traversal",
+         "predecessor traversal", "containers, optics, emit, node write"]
+tot = sum(out[:6])
+for n, v in zip(names, out):
+    print(f"{n:40s} {100.0 * v / tot:5.1f} %")
