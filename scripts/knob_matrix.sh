@@ -1,0 +1,10 @@
+#!/bin/bash
+# the GPU parity suite under every tuning knob (each run is a separate process: the knobs are read at commit)
+run() { echo "== $*"; env "$@" timeout -k 10 400 python -u -m pytest tests/test_gpu_parity.py -x -q --timeout 120 --timeout-method thread -m gpu 2>&1 | tail -1; }
+run RT_FRAME_SPLIT=2
+run RT_FRAME_SPLIT=3
+run RT_SHARE_LEAVES=0
+run RT_MAX_LEAF=1
+run RT_MAX_LEAF=4
+run RT_MAX_LEAF=15
+run RT_SAH_TRAV=1
