@@ -555,7 +555,7 @@ constexpr int LDS_STACK = RT_LDS_STACK;
 // The builders put the TOP_NODES nodes nearest each root first, breadth first, so the part
 // of a tree every ray walks sits in a few adjacent cache lines.
 constexpr int TOP_NODES = 128;
-constexpr int COOP_SLOTS = 64 * LEAF_MAX;
+constexpr int COOP_SLOTS = 64 * LEAF_MAX + 16;  // + the overhang of the last leaf's writes
 typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 struct TravStack {
@@ -887,12 +887,17 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
       const int off = upto - lcount;
       const int total = __builtin_amdgcn_readlane(upto, 63);
       bool hit_any = false;
-      // predicated stores, four at a time under one wave-uniform test
-      for (int j0 = 0; j0 < LEAF_MAX; j0 += 4) {
-        if (__ballot(lcount > j0) == 0ull) break;
+      // Slot -> owner table without a branch per slot: every lane with a leaf writes its id
+      // to LEAF_MAX slots from its first one, highest slot first.  What it writes beyond its
+      // own leaf lands on later lanes' slots and is overwritten by them afterwards: a slot's
+      // final writer is the lane with the latest start at or below it — its owner.  (Two
+      // lanes never write one slot in the same step: their starts differ.)
+      if (lcount > 0) {
 #pragma unroll
-        for (int j = j0; j < j0 + 4; j++)
-          if (j < lcount) st.owners[off + j] = (unsigned char)lane;
+        for (int j = LEAF_MAX - 1; j >= 0; j--) {
+          st.owners[off + j] = (unsigned char)lane;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // keep the stores in this order
+        }
       }
       wave_lds_fence();
       for (int base = 0; base < total; base += 64) {  // wave-uniform
