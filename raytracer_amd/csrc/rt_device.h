@@ -650,6 +650,36 @@ __device__ __forceinline__ bool accept_hit(double t, double u, double v, uint32_
   }
   return false;
 }
+// The same decision as accept_hit for a candidate that may not exist (`valid`), written as
+// selects: inside the wave-uniform collection loop of the cooperative leaf test a branch per
+// candidate costs more than the nine conditional moves.
+template <int MODE>
+__device__ __forceinline__ bool accept_hit_select(bool valid, double t, double u, double v, uint32_t ord, int m,
+                                                  int rec, Query& q) {
+  if (MODE == Q_CLOSEST) {
+    const bool take = valid & (t > 0.0) & ((t < q.hi) | ((t == q.hi) & (ord < q.hi_order)));
+    q.hi = take ? t : q.hi;
+    q.hi_order = take ? ord : q.hi_order;
+    q.mesh = take ? m : q.mesh;
+    q.tri = take ? rec : q.tri;
+    q.u = take ? u : q.u;
+    q.v = take ? v : q.v;
+    q.found = q.found | take;
+    return false;
+  } else if (MODE == Q_ANY) {
+    return valid & (t > 0.0) & (t < q.hi);
+  } else {
+    const bool below_k = (t < q.hi) | ((t == q.hi) & (ord < q.hi_order));
+    const bool above_best = !q.found | (q.best.t < t) | ((q.best.t == t) & (q.best.order < ord));
+    const bool take = valid & (rec != q.tri) & below_k & above_best;
+    q.best.t = take ? t : q.best.t;
+    q.best.order = take ? ord : q.best.order;
+    q.best.emit = take ? 0 : q.best.emit;
+    q.mesh = take ? m : q.mesh;
+    q.found = q.found | take;
+    return false;
+  }
+}
 template <int MODE, bool STATS>
 __device__ __forceinline__ bool test_tri(const DTri& T, uint32_t order_base, int m, int rec,
                                          const Ray& lr, const RayF&, Query& q, Counters& cnt) {
@@ -953,11 +983,9 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
           const int src = mine ? lo + k : lane;  // worker lane holding my next candidate
           const double t = __shfl(wt, src, 64), u = __shfl(wu, src, 64), v = __shfl(wv, src, 64);
           const uint32_t orig = (uint32_t)__shfl((int)worig, src, 64);
-          if (mine) {
-            mine &= mine - 1ull;
-            const int rec = lfirst + (base + lo + k - off);
-            if (accept_hit<MODE>(t, u, v, order_base + orig, m, tri_base + rec, q)) hit_any = true;
-          }
+          const int rec = lfirst + (base + lo + k - off);
+          hit_any |= accept_hit_select<MODE>(mine != 0ull, t, u, v, order_base + orig, m, tri_base + rec, q);
+          mine &= mine - 1ull;  // 0 stays 0
         }
       }
       // ---- owners move on
