@@ -850,6 +850,7 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
                                             Counters& cnt, TravStack& st) {
   const int lane = threadIdx.x & 63;
   bool satisfied = false;  // Q_ANY: this lane has its answer
+  if (__ballot(enabled) == 0ull) return false;  // no lane of the wave has a query (wave-uniform)
   for (int m = 0; m < S.n_meshes; m++) {
     const DMesh& M = S.meshes[m];
     Ray lr = ray;
