@@ -489,8 +489,11 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
   } else {
     active = i < n;
     if (active) {
-      // reflected rays fill the queue from the front, refracted rays from the back
-      const WfTask& T = tasks[i < n_front ? i : (long long)cap - 1 - (i - n_front)];
+      // Reflected rays fill the queue from the front, refracted rays from the back.  The
+      // refracted ones (inside glass: the longest walks) take the lowest indices, so they are
+      // dispatched first and the level's tail is made of cheap rays.
+      const long long n_back = n - n_front;
+      const WfTask& T = tasks[i < n_back ? (long long)cap - 1 - i : i - n_back];
       ray = {v3(T.o[0], T.o[1], T.o[2]), v3(T.d[0], T.d[1], T.d[2])};
       nd.parent = T.parent;
       nd.coef = T.coef;
