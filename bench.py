@@ -96,13 +96,18 @@ def main():
     ap.add_argument("--pipeline", default="wavefront", choices=["megakernel", "wavefront", "auto"])
     ap.add_argument("--mode", default="f64_parity", choices=["f64_parity", "f32_fast"],
                     help="f32_fast: triangle search in f32, everything else f64; reported with its pixel-match rate")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="frames in flight: step k is issued on stream k %% inflight with its own buffers, so the "
                          "tail of one frame's recursion level runs under the next frame (1 = strictly one at a time)")
+    ap.add_argument("--hw-queues", type=int, default=8,
+                    help="GPU_MAX_HW_QUEUES for this process (HIP's default is 4: more frames in flight than "
+                         "hardware queues share queues and serialise); 0 leaves the environment as it is")
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="host binned-SAH or device LBVH build")
     ap.add_argument("--cpu-pixels", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.hw_queues > 0:  # read by the HIP runtime when it starts: set before anything touches the GPU
+        os.environ["GPU_MAX_HW_QUEUES"] = str(min(args.hw_queues, 32))
 
     import torch
     import raytracer_amd as rt
@@ -255,7 +260,7 @@ def main():
             "scaling": "strong", "vs_baseline": None,
             "dtype": "f64" if args.mode == "f64_parity" else "f32 triangle search + f64 shading", "data": "synthetic",
             "config": {"workload": desc, "hsize": hs, "vsize": vs, "depth": 5, "mode": args.mode,
-                       "pipeline": args.pipeline, "frames_in_flight": F, "frame_latency_ms": frame_latency_ms, "bvh": args.bvh, "commit_ms": info["commit_ms"], "rays_per_frame": rays_per_frame,
+                       "pipeline": args.pipeline, "frames_in_flight": F, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "frame_latency_ms": frame_latency_ms, "bvh": args.bvh, "commit_ms": info["commit_ms"], "rays_per_frame": rays_per_frame,
                        "parallelism": f"tiles{rt.TILE}x{rt.TILE} round-robin over {n} GPU(s)" + (", RCCL gather to rank 0" if n > 1 else ""),
                        "triangles": info["n_triangles"], "bvh_nodes": info["n_bvh_nodes"],
                        "scene_bytes": info["device_bytes"], "frame_crc32": frame_crc},

@@ -1,11 +1,12 @@
 """Time one rank's share of the frame for N = 1, 2, 4, 8 on a single GPU (no exchange step)."""
 import os, sys, time
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("GPU_MAX_HW_QUEUES", "8") if os.environ.get("KEEP_HW_QUEUES") else "8"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import raytracer_amd as rt
 name, hs, vs = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else ("pawn", 1920, 1080)
 w = rt.World.example(name, hs, vs).commit()
-F = int(os.environ.get("INFLIGHT", "3"))
+F = int(os.environ.get("INFLIGHT", "4"))
 streams = [torch.cuda.Stream() for _ in range(F)]
 for n in (1, 2, 4, 8):
     per = max(rt.shard_tiles(hs, vs, s, n) for s in range(n))
