@@ -394,7 +394,7 @@ __device__ __forceinline__ void combine_node(const WfNode& N, WfNode* parents, d
 // Fills the level's result node and appends the child rays to the next level's queue:
 // reflected rays from the front, refracted rays from the back (world.rs:78-114).
 template <bool STATS>
-__device__ __forceinline__ void emit_result(const ShadeOut& so, const C3& surface, WfNode& nd, long long i,
+__device__ __forceinline__ bool emit_result(const ShadeOut& so, const C3& surface, WfNode& nd, long long i,
                                             WfTask* next, unsigned int* next_count, unsigned int next_cap,
                                             int spawn, Counters& cnt) {
   nd.surface[0] = surface.r;
@@ -444,6 +444,7 @@ __device__ __forceinline__ void emit_result(const ShadeOut& so, const C3& surfac
       cnt.depth0_skipped++;
     }
   }
+  return spawn && (so.do_reflect || so.do_refract);  // children will add to this node later
 }
 
 #ifdef RT_SECTION_TIMES
@@ -462,7 +463,7 @@ __device__ unsigned long long g_section_cycles[8];
 template <bool STATS, bool PRIMARY, bool FAST, bool COOP>
 __global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
 k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n, long long n_front,
-           unsigned int cap, WfNode* nodes, WfNode* direct_parents, WfTask* next,
+           unsigned int cap, WfNode* nodes, WfNode* parents, double* out_f64, uint8_t* out_u8, WfTask* next,
            unsigned int* next_count, unsigned int next_cap, int spawn, unsigned long long* counters) {
   static_assert(WF_BLOCK == 64, "the traversal stack is laid out for 64-lane blocks");
   RT_TRAV_STACK_COOP(st, S);
@@ -477,6 +478,7 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
   nd.flags = 0;
   nd.coef = 0.0;
   nd.parent = -1;
+  bool has_children = false;
   if (PRIMARY) {
     int px, py;
     long long oi;
@@ -554,7 +556,7 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
       if (need) containers_from<STATS>(S, ray, h, K, M.refractive_index, tf, tb, tm, n1, n2, cnt);
       ShadeOut so;
       finish_optics(M, ray, pr, n1, n2, so);
-      emit_result<STATS>(so, surface, nd, i, next, next_count, next_cap, spawn, cnt);
+      has_children = emit_result<STATS>(so, surface, nd, i, next, next_count, next_cap, spawn, cnt);
     }
   } else {
     if (active) {
@@ -562,16 +564,18 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
       if (trace_closest<STATS, FAST>(S, ray, h, cnt, st)) {
         ShadeOut so;
         shade_hit_local<STATS, FAST>(S, ray, h, so, cnt, st);
-        emit_result<STATS>(so, so.surface, nd, i, next, next_count, next_cap, spawn, cnt);
+        has_children = emit_result<STATS>(so, so.surface, nd, i, next, next_count, next_cap, spawn, cnt);
       }
     }
   }
-  if (!PRIMARY && direct_parents != nullptr) {
-    // deepest level: nothing will be added to this node, so its result goes straight into
-    // the parent's slot (the same expression k_wf_combine would evaluate on the stored node)
-    if (active) combine_node<false>(nd, direct_parents, nullptr, nullptr);
-  } else if (PRIMARY || active) {
+  // A call without children (a miss, a surface that spawns nothing, the deepest level) has its
+  // final value now: it goes straight to the pixel or into the parent's slot — the expression
+  // k_wf_combine would evaluate on the stored node — and the way back up skips the node.
+  if (has_children) {
     nodes[i] = nd;
+  } else if (PRIMARY || active) {
+    combine_node<PRIMARY>(nd, parents, out_f64, out_u8);
+    if (spawn) nodes[i].parent = -1;  // this level gets a combine pass: tell it to skip
   }
   RT_SECTION(5);
   flush_counters<STATS>(cnt, counters);
@@ -583,6 +587,7 @@ __global__ void k_wf_combine(const WfNode* nodes, long long n, WfNode* parents, 
                              uint8_t* out_u8) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (nodes[i].parent < 0) return;  // nothing to write, or written by the level kernel already
   combine_node<LEVEL0>(nodes[i], parents, out_f64, out_u8);
 }
 
@@ -1060,7 +1065,7 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
   unsigned int cap_in = 0;
   long long level_n[MAX_DEPTH + 1];
   int levels = 0;
-  bool direct_last = false;
+  bool spawned[MAX_DEPTH + 1] = {};
   int rc;
   for (int l = 0; l < depth; l++) {
     bool spawn = (l + 1 < depth);
@@ -1076,12 +1081,13 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     WfTask* tnext = spawn ? static_cast<WfTask*>(w->wf_tasks[l + 1]) : nullptr;
     unsigned int cap = spawn ? (unsigned int)std::min<size_t>(w->wf_task_cap[l + 1], 0xffffffffu) : 0u;
     unsigned int* cnt_next = w->wf_counts + 2 * (l + 1);
-    // the deepest level writes into its parents directly and needs no pass of its own on the way up
-    WfNode* direct = (!spawn && l > 0) ? static_cast<WfNode*>(w->wf_nodes[l - 1]) : nullptr;
-    if (direct) direct_last = true;
+    // calls without children write into their parents (or pixels) directly; a level that
+    // spawns nothing needs no pass of its own on the way up
+    WfNode* parents = (l > 0) ? static_cast<WfNode*>(w->wf_nodes[l - 1]) : nullptr;
+    spawned[l] = spawn;
 #define WF_LAUNCH(ST, PR, FA, CO)                                                                        \
   hipLaunchKernelGGL((k_wf_level<ST, PR, FA, CO>), grid, block, 0, st, s->d, dc, pm, tin, n, n_front, cap_in, \
-                     nodes, direct, tnext, cnt_next, cap, spawn ? 1 : 0, s->d_counters)
+                     nodes, parents, d_f64, d_u8, tnext, cnt_next, cap, spawn ? 1 : 0, s->d_counters)
 #define WF_LAUNCH2(ST, PR)              \
   do {                                  \
     if (fast && s->share_leaves)        \
@@ -1128,7 +1134,8 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     if (getenv("RT_TRACE_LEVELS"))  // queue length of every level of a newly planned frame
       for (int l = 0; l < levels; l++) fprintf(stderr, "rt: level %d: %lld tasks\n", l, level_n[l]);
   }
-  for (int l = levels - 1 - (direct_last ? 1 : 0); l >= 0; l--) {
+  for (int l = levels - 1; l >= 0; l--) {
+    if (!spawned[l]) continue;
     long long m = level_n[l];
     dim3 block(256), grid((unsigned)((m + 255) / 256));
     const WfNode* nodes = static_cast<const WfNode*>(w->wf_nodes[l]);
