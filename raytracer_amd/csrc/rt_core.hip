@@ -69,8 +69,10 @@ struct rt_scene {
     hipStream_t stream = nullptr;
     void* wf_tasks[MAX_DEPTH + 1] = {};
     void* wf_nodes[MAX_DEPTH + 1] = {};
+    void* wf_live[MAX_DEPTH + 1] = {};  // one byte per node: 1 = children will add to it
     size_t wf_task_cap[MAX_DEPTH + 1] = {};
     size_t wf_node_cap[MAX_DEPTH + 1] = {};
+    size_t wf_live_cap[MAX_DEPTH + 1] = {};
     unsigned int* wf_counts = nullptr;       // device, two counters per level
     unsigned int* wf_counts_host = nullptr;  // pinned
   };
@@ -463,7 +465,8 @@ __device__ unsigned long long g_section_cycles[8];
 template <bool STATS, bool PRIMARY, bool FAST, bool COOP>
 __global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
 k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n, long long n_front,
-           unsigned int cap, WfNode* nodes, WfNode* parents, double* out_f64, uint8_t* out_u8, WfTask* next,
+           unsigned int cap, WfNode* nodes, uint8_t* live, WfNode* parents, double* out_f64, uint8_t* out_u8,
+           WfTask* next,
            unsigned int* next_count, unsigned int next_cap, int spawn, unsigned long long* counters) {
   static_assert(WF_BLOCK == 64, "the traversal stack is laid out for 64-lane blocks");
   RT_TRAV_STACK_COOP(st, S);
@@ -575,19 +578,20 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
     nodes[i] = nd;
   } else if (PRIMARY || active) {
     combine_node<PRIMARY>(nd, parents, out_f64, out_u8);
-    if (spawn) nodes[i].parent = -1;  // this level gets a combine pass: tell it to skip
   }
+  // one dense byte per call tells the level's combine pass which nodes to touch at all
+  if (spawn && (PRIMARY || active)) live[i] = has_children ? 1 : 0;
   RT_SECTION(5);
   flush_counters<STATS>(cnt, counters);
 }
 
 // One level of the way back up (see k_wf_combine below).
 template <bool LEVEL0>
-__global__ void k_wf_combine(const WfNode* nodes, long long n, WfNode* parents, double* out_f64,
-                             uint8_t* out_u8) {
+__global__ void k_wf_combine(const WfNode* nodes, const uint8_t* live, long long n, WfNode* parents,
+                             double* out_f64, uint8_t* out_u8) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (nodes[i].parent < 0) return;  // nothing to write, or written by the level kernel already
+  if (!live[i]) return;  // no children: the level kernel has written this call's value already
   combine_node<LEVEL0>(nodes[i], parents, out_f64, out_u8);
 }
 
@@ -646,6 +650,7 @@ void rt_scene_destroy(rt_scene* s) {
       for (int l = 0; l <= MAX_DEPTH; l++) {
         if (w->wf_tasks[l]) (void)hipFree(w->wf_tasks[l]);
         if (w->wf_nodes[l]) (void)hipFree(w->wf_nodes[l]);
+        if (w->wf_live[l]) (void)hipFree(w->wf_live[l]);
       }
       if (w->wf_counts) (void)hipFree(w->wf_counts);
       if (w->wf_counts_host) (void)hipHostFree(w->wf_counts_host);
@@ -1070,6 +1075,7 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
   for (int l = 0; l < depth; l++) {
     bool spawn = (l + 1 < depth);
     if ((rc = wf_ensure(&w->wf_nodes[l], &w->wf_node_cap[l], (size_t)n, sizeof(WfNode)))) return rc;
+    if ((rc = wf_ensure(&w->wf_live[l], &w->wf_live_cap[l], (size_t)n, 1))) return rc;
     if (spawn) {
       if (2 * n > 0xfffffff0LL) return fail(RT_ERR_UNSUPPORTED, "ray queue exceeds 2^32 entries");
       if ((rc = wf_ensure(&w->wf_tasks[l + 1], &w->wf_task_cap[l + 1], (size_t)(2 * n), sizeof(WfTask))))
@@ -1087,7 +1093,8 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     spawned[l] = spawn;
 #define WF_LAUNCH(ST, PR, FA, CO)                                                                        \
   hipLaunchKernelGGL((k_wf_level<ST, PR, FA, CO>), grid, block, 0, st, s->d, dc, pm, tin, n, n_front, cap_in, \
-                     nodes, parents, d_f64, d_u8, tnext, cnt_next, cap, spawn ? 1 : 0, s->d_counters)
+                     nodes, static_cast<uint8_t*>(w->wf_live[l]), parents, d_f64, d_u8, tnext, cnt_next, cap,   \
+                     spawn ? 1 : 0, s->d_counters)
 #define WF_LAUNCH2(ST, PR)              \
   do {                                  \
     if (fast && s->share_leaves)        \
@@ -1139,10 +1146,11 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     long long m = level_n[l];
     dim3 block(256), grid((unsigned)((m + 255) / 256));
     const WfNode* nodes = static_cast<const WfNode*>(w->wf_nodes[l]);
+    const uint8_t* live = static_cast<const uint8_t*>(w->wf_live[l]);
     if (l == 0)
-      hipLaunchKernelGGL(k_wf_combine<true>, grid, block, 0, st, nodes, m, (WfNode*)nullptr, d_f64, d_u8);
+      hipLaunchKernelGGL(k_wf_combine<true>, grid, block, 0, st, nodes, live, m, (WfNode*)nullptr, d_f64, d_u8);
     else
-      hipLaunchKernelGGL(k_wf_combine<false>, grid, block, 0, st, nodes, m,
+      hipLaunchKernelGGL(k_wf_combine<false>, grid, block, 0, st, nodes, live, m,
                          static_cast<WfNode*>(w->wf_nodes[l - 1]), d_f64, d_u8);
     HIP_TRY(hipGetLastError());
     s->launches++;
