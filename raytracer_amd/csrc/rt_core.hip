@@ -209,9 +209,9 @@ struct PixelMap {
   int out_row_major, out_k_mul, out_k_add;
 };
 
-__device__ __forceinline__ bool lane_pixel(const PixelMap& pm, int& px, int& py, long long& out_index) {
+__device__ __forceinline__ bool lane_pixel(const PixelMap& pm, int& px, int& py, long long& out_index,
+                                           long long b = blockIdx.x) {
   constexpr int PATCHES = (RT_TILE / 8) * (RT_TILE / 8);
-  long long b = blockIdx.x;
   long long k = b / PATCHES;  // local tile
   int patch = (int)(b % PATCHES);
   long long tile = pm.tile_first + k * pm.tile_step;
@@ -462,6 +462,26 @@ __device__ unsigned long long g_section_cycles[8];
 #define RT_SECTION(k) do { } while (0)
 #endif
 
+// The hardware deals consecutive workgroups of a launch round-robin to the 8 XCDs, each
+// with an L2 of its own.  Taken as they come, the 16 waves of one 32x32 tile (and the runs of
+// neighbouring rays of a deeper level) would be spread over all eight L2s, and each would
+// fetch the same nodes and triangles.  This permutation of the block index gives every XCD
+// runs of RT_XCD_CHUNK consecutive waves instead: within each group of 8 * CHUNK blocks, the
+// blocks that land on XCD x (index % 8 == x) take the x-th run.  The incomplete group at the
+// end of a launch keeps its order.  0 switches the permutation off.
+#ifndef RT_XCD_CHUNK
+#define RT_XCD_CHUNK 16
+#endif
+__device__ __forceinline__ long long wf_block_index() {
+  const long long b = blockIdx.x;
+  if (RT_XCD_CHUNK == 0) return b;
+  constexpr long long G = 8ll * (RT_XCD_CHUNK ? RT_XCD_CHUNK : 1);
+  const long long g = b / G;
+  if ((g + 1) * G > (long long)gridDim.x) return b;
+  const long long r = b - g * G;
+  return g * G + (r % 8) * (G / 8) + r / 8;
+}
+
 template <bool STATS, bool PRIMARY, bool FAST, bool COOP>
 __global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
 k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n, long long n_front,
@@ -474,7 +494,8 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
   unsigned long long section_t_ = __builtin_readcyclecounter();
 #endif
   Counters cnt{};
-  long long i = (long long)blockIdx.x * WF_BLOCK + threadIdx.x;
+  const long long block = wf_block_index();
+  long long i = block * WF_BLOCK + threadIdx.x;
   bool active;
   Ray ray = {v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 1.0)};
   WfNode nd;
@@ -485,7 +506,7 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
   if (PRIMARY) {
     int px, py;
     long long oi;
-    active = lane_pixel(pm, px, py, oi);
+    active = lane_pixel(pm, px, py, oi, block);
     if (active) {
       ray = ray_for_pixel(cam, px, py);
       nd.parent = (int32_t)oi;
