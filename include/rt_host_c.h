@@ -67,6 +67,9 @@ int rth_render(rth_world*, int depth, int mode, int pipeline, double* out_rgb_f6
                uint8_t* out_rgb_u8, rt_stats* stats);
 /* Canvas::write_to_ppm, canvas.rs:29-44 */
 int rth_write_ppm(const char* path, int width, int height, const uint8_t* rgb);
+/* The same image as an 8-bit RGB PNG, the format of the reference's renders/ directory
+ * (the reference itself only writes PPM, canvas.rs:29-44). */
+int rth_write_png(const char* path, int width, int height, const uint8_t* rgb);
 
 /* math pre-computation (known-answer tests): Matrix::inverse (matrix.rs:154-168),
  * determinant (117-128), mat x mat (33-53), constructors (170-240; kind 0 translation,

@@ -167,6 +167,7 @@ def lib():
     L.rth_scene.restype = vp
     L.rth_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, u8p, C.POINTER(Stats)]
     L.rth_write_ppm.argtypes = [C.c_char_p, C.c_int, C.c_int, u8p]
+    L.rth_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, u8p]
     L.rth_mat_inverse.argtypes = [dp, C.c_int, dp]
     L.rth_mat_determinant.argtypes = [dp, C.c_int]
     L.rth_mat_determinant.restype = C.c_double
@@ -350,6 +351,14 @@ def detile_u8(d_tiles, nshards, tiles_per_shard, hsize, vsize, d_image, stream=N
                             C.c_void_p(d_image), C.c_void_p(stream or 0))
     if rc != 0:
         raise RtError(f"rt_detile_u8: {lib().rt_last_error().decode()}")
+
+
+def write_png(path, rgb):
+    """The quantised image as an 8-bit RGB PNG (the format of the reference's renders/)."""
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = a.shape
+    if lib().rth_write_png(path.encode(), w, h, a.ctypes.data_as(C.POINTER(C.c_uint8))) != 0:
+        raise RtError(f"cannot write {path}")
 
 
 def write_ppm(path, rgb):

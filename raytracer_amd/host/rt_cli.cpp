@@ -2,7 +2,7 @@
 //   -t/--threads N   accepted for compatibility (main.rs:19-26); the GPU needs no thread count
 //   -e/--example X   "cover" (default) | "pawn" | "tea set"   (main.rs:27-35, 46-51)
 // Additions: --width/--height (override the example's size), --gpu N, --obj-dir DIR,
-// --out FILE (default canvas.ppm, main.rs:54), --stats.
+// --out FILE (default canvas.ppm, main.rs:54; a name ending in .png is written as PNG), --stats.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -56,7 +56,8 @@ int main(int argc, char** argv) {
     if (stats) opt.stats = &st;
     std::printf("Rendering image on GPU %d\n", gpu < 0 ? 0 : gpu);
     rt::Canvas image = rt::render(scene.first, scene.second, opt);
-    if (!image.write_to_ppm(out)) {
+    const bool png = out.size() >= 4 && out.compare(out.size() - 4, 4, ".png") == 0;
+    if (!(png ? image.write_to_png(out) : image.write_to_ppm(out))) {
       std::fprintf(stderr, "could not create file %s\n", out.c_str());
       return 1;
     }

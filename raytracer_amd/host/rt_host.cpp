@@ -290,6 +290,95 @@ bool Canvas::write_to_ppm(const std::string& file_name) const {
   return std::fclose(f) == 0;
 }
 
+namespace {
+struct Crc32 {  // CRC-32 of the PNG chunk layer (polynomial 0xedb88320, reflected)
+  uint32_t table[256];
+  Crc32() {
+    for (uint32_t n = 0; n < 256; n++) {
+      uint32_t c = n;
+      for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+      table[n] = c;
+    }
+  }
+  uint32_t update(uint32_t crc, const uint8_t* p, size_t n) const {
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    return crc;
+  }
+};
+void put_be32(std::vector<uint8_t>& v, uint32_t x) {
+  v.push_back((uint8_t)(x >> 24));
+  v.push_back((uint8_t)(x >> 16));
+  v.push_back((uint8_t)(x >> 8));
+  v.push_back((uint8_t)x);
+}
+bool write_chunk(FILE* f, const Crc32& crc, const char type[4], const std::vector<uint8_t>& data) {
+  std::vector<uint8_t> head;
+  put_be32(head, (uint32_t)data.size());
+  head.insert(head.end(), type, type + 4);
+  uint32_t c = crc.update(0xffffffffu, head.data() + 4, 4);
+  c = crc.update(c, data.data(), data.size()) ^ 0xffffffffu;
+  std::vector<uint8_t> tail;
+  put_be32(tail, c);
+  return std::fwrite(head.data(), 1, head.size(), f) == head.size() &&
+         std::fwrite(data.data(), 1, data.size(), f) == data.size() &&
+         std::fwrite(tail.data(), 1, tail.size(), f) == tail.size();
+}
+}  // namespace
+
+bool Canvas::write_to_png(const std::string& file_name) const {
+  if (width <= 0 || height <= 0 || rgb8.size() != (size_t)width * height * 3) return false;
+  // one IDAT chunk holds the whole zlib stream: its length field is 32 bits
+  const size_t row = (size_t)width * 3 + 1, raw = row * (size_t)height;
+  const size_t blocks = (raw + 65534) / 65535;
+  if (raw + 5 * blocks + 6 > 0x7fffffffu) return false;
+  FILE* f = std::fopen(file_name.c_str(), "wb");
+  if (!f) return false;
+  const Crc32 crc;
+  static const uint8_t signature[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+  bool ok = std::fwrite(signature, 1, 8, f) == 8;
+  std::vector<uint8_t> ihdr;
+  put_be32(ihdr, (uint32_t)width);
+  put_be32(ihdr, (uint32_t)height);
+  const uint8_t kind[5] = {8, 2, 0, 0, 0};  // 8 bits per sample, truecolour, deflate, filter set 0, no interlace
+  ihdr.insert(ihdr.end(), kind, kind + 5);
+  ok = ok && write_chunk(f, crc, "IHDR", ihdr);
+  // scanlines with filter type 0, then a zlib stream of stored blocks around them
+  std::vector<uint8_t> lines(raw);
+  uint32_t a = 1, b = 0;  // Adler-32 of the scanlines
+  for (int y = 0; y < height; y++) {
+    uint8_t* dst = lines.data() + (size_t)y * row;
+    dst[0] = 0;
+    std::memcpy(dst + 1, rgb8.data() + (size_t)y * width * 3, (size_t)width * 3);
+  }
+  for (size_t i = 0; i < raw;) {
+    const size_t n = std::min<size_t>(raw - i, 5552);  // largest run before the sums must be reduced
+    for (size_t k = 0; k < n; k++) {
+      a += lines[i + k];
+      b += a;
+    }
+    a %= 65521u;
+    b %= 65521u;
+    i += n;
+  }
+  std::vector<uint8_t> z;
+  z.reserve(raw + 5 * blocks + 6);
+  z.push_back(0x78);
+  z.push_back(0x01);
+  for (size_t i = 0; i < raw; i += 65535) {
+    const size_t n = std::min<size_t>(raw - i, 65535);
+    z.push_back(i + n == raw ? 1 : 0);  // BFINAL, BTYPE = 00 (stored)
+    z.push_back((uint8_t)(n & 0xff));
+    z.push_back((uint8_t)(n >> 8));
+    z.push_back((uint8_t)(~n & 0xff));
+    z.push_back((uint8_t)((~n >> 8) & 0xff));
+    z.insert(z.end(), lines.begin() + (long)i, lines.begin() + (long)(i + n));
+  }
+  put_be32(z, (b << 16) | a);
+  ok = ok && write_chunk(f, crc, "IDAT", z);
+  ok = ok && write_chunk(f, crc, "IEND", {});
+  return (std::fclose(f) == 0) && ok;
+}
+
 // ---- OBJ ---------------------------------------------------------------------------------
 namespace {
 // `str::lines()`: split at '\n' and drop one trailing '\r'

@@ -176,6 +176,9 @@ struct Canvas {
   std::vector<uint8_t> rgb8;
   std::vector<double> rgb;
   bool write_to_ppm(const std::string& file_name) const;  // P3 text, canvas.rs:29-44
+  // 8-bit RGB PNG (the format of the reference's renders/): the quantised image, unfiltered
+  // rows in stored deflate blocks, so writing costs one pass over the bytes.
+  bool write_to_png(const std::string& file_name) const;
 };
 
 // obj_parser.rs:9-68

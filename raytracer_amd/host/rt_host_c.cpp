@@ -225,6 +225,15 @@ int rth_write_ppm(const char* path, int width, int height, const uint8_t* rgb) {
   return c.write_to_ppm(path) ? 0 : -1;
 }
 
+int rth_write_png(const char* path, int width, int height, const uint8_t* rgb) {
+  if (!path || !rgb || width <= 0 || height <= 0) return -1;
+  Canvas c;
+  c.width = width;
+  c.height = height;
+  c.rgb8.assign(rgb, rgb + (size_t)width * height * 3);
+  return c.write_to_png(path) ? 0 : -1;
+}
+
 int rth_mat_inverse(const double* m, int size, double* out) {
   return guarded([&] {
     Matrix::from_rows(m, size).inverse().to_rows(out);

@@ -235,6 +235,13 @@ def test_cli_writes_the_reference_ppm(rt, O, tmp_path, pipeline):
     O.write_ppm(str(want), ou8)
     assert out.read_bytes() == want.read_bytes()
     assert out.read_bytes().startswith(b"P3\n160 90\n255\n")
+    # the same frame as a PNG (an output name ending in .png)
+    png = tmp_path / "cli.png"
+    r = subprocess.run([os.path.join(repo, "raytracer_amd", "rt_cli"), "-e", "pawn", "--width", "160", "--height", "90",
+                        "--obj-dir", os.path.join(repo, "assets", "obj"), "--out", str(png)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(O.read_png_rgb8(str(png)), ou8)
 
 
 # ---- random and adversarial scenes -------------------------------------------------------------

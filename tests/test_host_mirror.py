@@ -152,3 +152,26 @@ def test_ppm_writer_format(rt, tmp_path):  # canvas.rs:29-44
     p = str(tmp_path / "c.ppm")
     rt.write_ppm(p, rgb)
     assert open(p).read() == "P3\n3 2\n255\n0 1 2 3 4 5 6 7 8 \n9 10 11 12 13 14 15 16 17 \n"
+
+
+@pytest.mark.parametrize("size", [(1, 1), (7, 3), (300, 200), (1000, 90)])
+def test_png_writer_round_trip(rt, O, tmp_path, size):
+    """Canvas::write_to_png against the test suite's PNG decoder (the one that reads the
+    reference's renders): sizes below, at and above one stored deflate block (65535 bytes)."""
+    w, h = size
+    rgb = np.random.default_rng(w * 1000 + h).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    p = str(tmp_path / "c.png")
+    rt.write_png(p, rgb)
+    assert np.array_equal(O.read_png_rgb8(p), rgb)  # inflates the stream: Adler-32 checked by zlib
+    import struct
+    import zlib
+    b, pos, kinds = open(p, "rb").read(), 8, []
+    while pos < len(b):  # every chunk's CRC-32, which the decoder above does not look at
+        ln, typ = struct.unpack(">I4s", b[pos:pos + 8])
+        crc, = struct.unpack(">I", b[pos + 8 + ln:pos + 12 + ln])
+        assert crc == zlib.crc32(b[pos + 4:pos + 8 + ln])
+        kinds.append(typ)
+        pos += 12 + ln
+    assert kinds == [b"IHDR", b"IDAT", b"IEND"] and pos == len(b)
+    with pytest.raises(rt.RtError):
+        rt.write_png(str(tmp_path / "no_such_dir" / "c.png"), rgb)
