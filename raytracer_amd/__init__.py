@@ -313,6 +313,22 @@ class World:
         shape = (cam.vsize, cam.hsize, 3)
         return u8.reshape(shape), (f64.reshape(shape) if want_f64 else None), st
 
+    def render_sequence(self, cameras, depth=5, mode=MODE_F64_PARITY, pipeline=None, inflight=4):
+        """rth_render_sequence: one u8 HxWx3 image per camera (CameraABI), frames in flight."""
+        pipeline = DEFAULT_PIPELINE if pipeline is None else pipeline
+        cams = (CameraABI * len(cameras))(*cameras)
+        sizes = [c.hsize * c.vsize * 3 for c in cameras]
+        buf = np.zeros(sum(sizes), dtype=np.uint8)
+        rc = self.L.rth_render_sequence(self.h, cams, len(cameras), depth, mode, pipeline, inflight,
+                                        buf.ctypes.data_as(C.POINTER(C.c_uint8)))
+        if rc != 0:
+            self._err("render_sequence")
+        out, off = [], 0
+        for c, n in zip(cameras, sizes):
+            out.append(buf[off:off + n].reshape(c.vsize, c.hsize, 3))
+            off += n
+        return out
+
     def render_device(self, d_u8=None, d_f64=None, stream=None, depth=5, mode=MODE_F64_PARITY,
                       pipeline=None, tile_first=0, tile_step=1, want_stats=False,
                       cam=None):

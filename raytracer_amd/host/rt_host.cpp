@@ -2,6 +2,8 @@
 // OBJ loading, the example scenes, flattening into the C ABI, PPM output.
 #include "rt_host.h"
 
+#include <hip/hip_runtime.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -692,6 +694,96 @@ Canvas render(const Camera& camera, const World& world, const RenderOptions& opt
   DeviceScene ds;
   if (!ds.commit(world, opt.device)) throw std::runtime_error("render: " + ds.error());
   return render(camera, ds, opt);
+}
+
+int render_sequence_raw(rt_scene* scene, const rt_camera* cameras, int n, int depth, int mode,
+                        int pipeline, int inflight, uint8_t* const* out) {
+  if (!scene || n < 0 || (n > 0 && (!cameras || !out))) return RT_ERR_ARG;
+  rt_scene_info info;
+  int rc = rt_scene_get_info(scene, &info);
+  if (rc != RT_OK) return rc;
+  if (n == 0) return RT_OK;
+  const int F = std::max(1, std::min(std::min(inflight, 8), n));
+  size_t largest = 0;
+  for (int k = 0; k < n; k++) {
+    if (cameras[k].hsize <= 0 || cameras[k].vsize <= 0 || !out[k]) return RT_ERR_ARG;
+    largest = std::max(largest, (size_t)cameras[k].hsize * cameras[k].vsize * 3);
+  }
+  int previous = 0;
+  if (hipGetDevice(&previous) != hipSuccess || hipSetDevice(info.device) != hipSuccess) return RT_ERR_HIP;
+  struct Slot {
+    hipStream_t stream = nullptr;
+    uint8_t* device = nullptr;
+    uint8_t* pinned = nullptr;
+    int frame = -1;  // the frame whose image is on its way into `pinned`
+  };
+  std::vector<Slot> slots(F);
+  bool hip_ok = true;
+  for (Slot& s : slots)
+    hip_ok = hip_ok && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+             hipMalloc((void**)&s.device, largest) == hipSuccess &&
+             hipHostMalloc((void**)&s.pinned, largest, hipHostMallocDefault) == hipSuccess;
+  // waits for the frame a slot holds and hands its image to the caller
+  auto collect = [&](Slot& s) {
+    if (s.frame < 0) return true;
+    if (hipStreamSynchronize(s.stream) != hipSuccess) return false;
+    const rt_camera& c = cameras[s.frame];
+    std::memcpy(out[s.frame], s.pinned, (size_t)c.hsize * c.vsize * 3);
+    s.frame = -1;
+    return true;
+  };
+  rc = hip_ok ? RT_OK : RT_ERR_HIP;
+  for (int k = 0; k < n && rc == RT_OK; k++) {
+    Slot& s = slots[k % F];
+    if (!collect(s)) {
+      rc = RT_ERR_HIP;
+      break;
+    }
+    rc = rt_render_device(scene, &cameras[k], depth, mode, pipeline, 0, 1, nullptr, s.device, s.stream, 0);
+    if (rc != RT_OK) break;
+    if (hipMemcpyAsync(s.pinned, s.device, (size_t)cameras[k].hsize * cameras[k].vsize * 3,
+                       hipMemcpyDeviceToHost, s.stream) != hipSuccess) {
+      rc = RT_ERR_HIP;
+      break;
+    }
+    s.frame = k;
+  }
+  // drain in frame order; on an error the streams are still waited for before anything is freed
+  for (int j = 0; j < F; j++) {
+    Slot& s = slots[(std::max(n, F) - F + j) % F];
+    if (rc == RT_OK) {
+      if (!collect(s)) rc = RT_ERR_HIP;
+    } else if (s.stream) {
+      (void)hipStreamSynchronize(s.stream);
+    }
+  }
+  for (Slot& s : slots) {
+    if (s.pinned) (void)hipHostFree(s.pinned);
+    if (s.device) (void)hipFree(s.device);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+  }
+  (void)hipSetDevice(previous);
+  return rc;
+}
+
+std::vector<Canvas> render_sequence(const std::vector<Camera>& cameras, DeviceScene& scene,
+                                    const RenderOptions& opt, int inflight) {
+  std::vector<Canvas> frames(cameras.size());
+  std::vector<rt_camera> abi(cameras.size());
+  std::vector<uint8_t*> out(cameras.size());
+  for (size_t k = 0; k < cameras.size(); k++) {
+    abi[k] = cameras[k].to_abi();
+    frames[k].width = cameras[k].hsize;
+    frames[k].height = cameras[k].vsize;
+    frames[k].rgb8.resize((size_t)cameras[k].hsize * cameras[k].vsize * 3);
+    out[k] = frames[k].rgb8.data();
+  }
+  int rc = render_sequence_raw(scene.handle(), abi.data(), (int)abi.size(), opt.depth, opt.mode, opt.pipeline,
+                               inflight, out.data());
+  if (rc != RT_OK)
+    throw std::runtime_error(std::string("render_sequence: ") + (rc == RT_ERR_HIP ? "HIP runtime call failed; " : "") +
+                             rt_last_error());
+  return frames;
 }
 
 // ---- examples (examples.rs) -----------------------------------------------------------------

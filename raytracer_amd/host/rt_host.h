@@ -217,6 +217,23 @@ struct RenderOptions {
 Canvas render(const Camera& camera, const World& world, const RenderOptions& opt = RenderOptions());
 Canvas render(const Camera& camera, DeviceScene& scene, const RenderOptions& opt = RenderOptions());
 
+// A camera sweep over one committed scene (not in the reference, whose command line renders
+// one frame per process): frame k is rendered for cameras[k], up to `inflight` frames at a
+// time on streams of their own, each with its own device and pinned host buffer, so the thin
+// tail of one frame's recursion level runs under the next frame and the copy back to the
+// host under both.  The frames are the ones render() returns for the same cameras.  Start
+// the process with GPU_MAX_HW_QUEUES=8 to give four frames in flight a hardware queue each.
+// A camera the scene has not rendered before is issued with one host read-back per recursion
+// level on the wavefront pipeline (the queue lengths size the next launch), which holds the
+// issuing thread until that frame is nearly done: a sweep of all-new cameras overlaps only its
+// copies, a loop that comes back to cameras it has seen (a turntable) overlaps fully.
+std::vector<Canvas> render_sequence(const std::vector<Camera>& cameras, DeviceScene& scene,
+                                    const RenderOptions& opt = RenderOptions(), int inflight = 4);
+// The same over plain camera structs, into caller-provided images (out[k]: hsize*vsize*3
+// bytes of frame k).  Returns RT_OK or an RT_ERR_* code (rt_last_error() has the text).
+int render_sequence_raw(rt_scene* scene, const rt_camera* cameras, int n, int depth, int mode,
+                        int pipeline, int inflight, uint8_t* const* out);
+
 // examples.rs:19-404.  obj_dir holds pawn-chess.obj, teapot.obj, teacup.obj (the reference
 // reads ./obj/ relative to the working directory).  hsize/vsize 0 keep the example's size.
 namespace examples {

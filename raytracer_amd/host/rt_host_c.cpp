@@ -216,6 +216,32 @@ int rth_render(rth_world* w, int depth, int mode, int pipeline, double* out_rgb_
   });
 }
 
+int rth_render_sequence(rth_world* w, const rt_camera* cameras, int n, int depth, int mode, int pipeline,
+                        int inflight, uint8_t* out_rgb_u8) {
+  if (!w || !w->committed) {
+    g_herr = "world not committed";
+    return -1;
+  }
+  if (n < 0 || (n > 0 && (!cameras || !out_rgb_u8))) {
+    g_herr = "bad argument";
+    return -1;
+  }
+  return guarded([&] {
+    std::vector<uint8_t*> out((size_t)n);
+    size_t off = 0;
+    for (int k = 0; k < n; k++) {
+      out[k] = out_rgb_u8 + off;
+      if (cameras[k].hsize > 0 && cameras[k].vsize > 0) off += (size_t)cameras[k].hsize * cameras[k].vsize * 3;
+    }
+    int rc = render_sequence_raw(w->device.handle(), cameras, n, depth, mode, pipeline, inflight, out.data());
+    if (rc != RT_OK) {
+      g_herr = rc == RT_ERR_HIP ? "HIP runtime call failed" : rt_last_error();
+      return -rc;
+    }
+    return 0;
+  });
+}
+
 int rth_write_ppm(const char* path, int width, int height, const uint8_t* rgb) {
   if (!path || !rgb || width <= 0 || height <= 0) return -1;
   Canvas c;

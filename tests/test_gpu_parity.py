@@ -244,6 +244,41 @@ def test_cli_writes_the_reference_ppm(rt, O, tmp_path, pipeline):
     assert np.array_equal(O.read_png_rgb8(str(png)), ou8)
 
 
+def test_camera_sweep_equals_single_frames(rt, O, pipeline):
+    """render_sequence (frames in flight on streams of the library's own, pinned copies back):
+    every frame equals the one rendered alone, for new cameras and for cameras seen before."""
+    import ctypes as C
+    import torch
+    pipe = rt.PIPELINE_WAVEFRONT if pipeline == "wavefront" else rt.PIPELINE_MEGAKERNEL
+    w = rt.World.example("pawn", 96, 54)
+    base = w.camera_abi()
+    w.commit()
+    cams = []
+    for k in range(7):  # the example's camera with its inverse turned about the y axis, two sizes
+        a = 0.15 * k
+        rot = np.array([[math.cos(a), 0, math.sin(a), 0], [0, 1, 0, 0], [-math.sin(a), 0, math.cos(a), 0],
+                        [0, 0, 0, 1]], dtype=np.float64)
+        c = rt.CameraABI()
+        C.memmove(C.byref(c), C.byref(base), C.sizeof(c))
+        inv = rot @ np.array(list(base.inv), dtype=np.float64).reshape(4, 4)
+        c.inv[:] = inv.reshape(16)
+        cams.append(c)
+    alone = []
+    for c in cams:
+        buf = torch.zeros((c.vsize, c.hsize, 3), dtype=torch.uint8, device="cuda")
+        w.render_device(d_u8=buf.data_ptr(), pipeline=pipe, cam=c)
+        torch.cuda.synchronize()
+        alone.append(buf.cpu().numpy())
+    assert any(not np.array_equal(alone[0], a) for a in alone[1:])
+    for inflight in (1, 3, 8):
+        for rep in range(2):
+            got = w.render_sequence(cams, pipeline=pipe, inflight=inflight)
+            assert len(got) == len(cams)
+            for g, a in zip(got, alone):
+                assert np.array_equal(g, a)
+    assert w.render_sequence([], pipeline=pipe) == []
+
+
 # ---- random and adversarial scenes -------------------------------------------------------------
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_scenes(rt, O, seed):
