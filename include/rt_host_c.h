@@ -71,6 +71,11 @@ int rth_render(rth_world*, int depth, int mode, int pipeline, double* out_rgb_f6
  * hsize*vsize*3 bytes of cameras[k]); they equal what rth_render gives for each camera. */
 int rth_render_sequence(rth_world*, const rt_camera* cameras, int n, int depth, int mode,
                         int pipeline, int inflight, uint8_t* out_rgb_u8);
+/* A sweep issues a camera the scene has not seen without waiting for its ray-queue lengths,
+ * sizing launches from the latest frame of the same size instead, and renders the frame again
+ * if a queue outgrew that estimate.  Totals since commit: frames issued that way, and how many
+ * of them were rendered again. */
+int rth_sweep_counters(rth_world*, int64_t* issued_on_estimate, int64_t* rendered_again);
 /* Canvas::write_to_ppm, canvas.rs:29-44 */
 int rth_write_ppm(const char* path, int width, int height, const uint8_t* rgb);
 /* The same image as an 8-bit RGB PNG, the format of the reference's renders/ directory

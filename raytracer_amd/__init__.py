@@ -329,6 +329,13 @@ class World:
             off += n
         return out
 
+    def sweep_counters(self):
+        """rth_sweep_counters: (frames issued on an estimate, of those rendered again)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        if self.L.rth_sweep_counters(self.h, C.byref(a), C.byref(b)) != 0:
+            self._err("sweep_counters")
+        return a.value, b.value
+
     def render_device(self, d_u8=None, d_f64=None, stream=None, depth=5, mode=MODE_F64_PARITY,
                       pipeline=None, tile_first=0, tile_step=1, want_stats=False,
                       cam=None):

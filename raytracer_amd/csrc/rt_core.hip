@@ -15,6 +15,7 @@
 #include "../../include/rt_core.h"
 #include "rt_bvh.h"
 #include "rt_device.h"
+#include "rt_internal.h"
 
 using namespace rtd;
 
@@ -75,7 +76,24 @@ struct rt_scene {
     size_t wf_live_cap[MAX_DEPTH + 1] = {};
     unsigned int* wf_counts = nullptr;       // device, two counters per level
     unsigned int* wf_counts_host = nullptr;  // pinned
+    // a frame issued on an estimate whose counters are on their way to wf_counts_host
+    bool estimate_pending = false;
+    uint64_t estimate_key = 0;
+    int estimate_depth = 0;
+    long long estimate_n0 = 0;
   };
+  // set around a call by rt_render_device_estimated: unseen frames may be issued on an estimate
+  bool allow_estimates = false;
+  bool estimated_fast = false;
+  // camera sweeps (rti::sweep_slot): streams and image buffers of the scene's own, grow only
+  struct SweepSlot {
+    hipStream_t stream = nullptr;
+    uint8_t* device = nullptr;
+    uint8_t* pinned = nullptr;
+    size_t bytes = 0;
+  };
+  std::vector<SweepSlot> sweep_slots;
+  long long n_estimated = 0, n_estimate_missed = 0;  // frames issued on an estimate / of those, rendered again
   std::vector<WfState*> wf_states;  // at most WF_MAX_STREAMS; beyond that streams share the last one
   // queue lengths of the last frame rendered with host read-backs: the same frame (camera,
   // shard, depth, mode) is then issued again without any synchronisation
@@ -89,6 +107,8 @@ struct rt_scene {
   struct WfPlan {
     uint64_t key = 0;
     int levels = 0;
+    int depth = 0;
+    bool fast = false;
     long long n[MAX_DEPTH + 1] = {}, front[MAX_DEPTH + 1] = {};
   };
   std::vector<WfPlan> wf_plans;  // most recent last, at most WF_MAX_PLANS
@@ -487,7 +507,8 @@ __global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
 k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n, long long n_front,
            unsigned int cap, WfNode* nodes, uint8_t* live, WfNode* parents, double* out_f64, uint8_t* out_u8,
            WfTask* next,
-           unsigned int* next_count, unsigned int next_cap, int spawn, unsigned long long* counters) {
+           unsigned int* next_count, unsigned int next_cap, int spawn, unsigned long long* counters,
+           const unsigned int* counts_in, unsigned int* overflow) {
   static_assert(WF_BLOCK == 64, "the traversal stack is laid out for 64-lane blocks");
   RT_TRAV_STACK_COOP(st, S);
 #ifdef RT_SECTION_TIMES
@@ -513,6 +534,21 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
       if (STATS) cnt.rays_primary++;
     }
   } else {
+    // A frame issued on an estimate (see render_wavefront) learns the queue's length here, from
+    // the counters the previous level left on the device; `n` is then what the grid and the
+    // buffers were sized for.  A queue longer than that cannot be rendered by this launch: the
+    // level is skipped and the frame marked as incomplete for the host to render again.
+    if (counts_in) {
+      const long long have_front = counts_in[0], have = have_front + counts_in[1];
+      if (have > n) {
+        if (i == 0) *overflow = 1u;
+        n = 0;
+      } else {
+        n = have;
+        n_front = have_front;
+      }
+      if (block * WF_BLOCK >= n) return;  // wave-uniform
+    }
     active = i < n;
     if (active) {
       // Reflected rays fill the queue from the front, refracted rays from the back.  The
@@ -609,8 +645,13 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
 // One level of the way back up (see k_wf_combine below).
 template <bool LEVEL0>
 __global__ void k_wf_combine(const WfNode* nodes, const uint8_t* live, long long n, WfNode* parents,
-                             double* out_f64, uint8_t* out_u8) {
+                             double* out_f64, uint8_t* out_u8, const unsigned int* counts_in,
+                             const unsigned int* overflow) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // A frame issued on an estimate: the level's true length is on the device; after a level
+  // has outgrown its estimate the nodes of the levels behind it are not this frame's.
+  if (overflow && *overflow) return;
+  if (counts_in) n = min(n, (long long)counts_in[0] + (long long)counts_in[1]);
   if (i >= n) return;
   if (!live[i]) return;  // no children: the level kernel has written this call's value already
   combine_node<LEVEL0>(nodes[i], parents, out_f64, out_u8);
@@ -667,6 +708,11 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->split_fork) (void)hipEventDestroy(s->split_fork);
     for (hipEvent_t e : s->split_joined) (void)hipEventDestroy(e);
     for (hipStream_t q : s->split_streams) (void)hipStreamDestroy(q);
+    for (rt_scene::SweepSlot& q : s->sweep_slots) {
+      if (q.stream) (void)hipStreamDestroy(q.stream);
+      if (q.device) (void)hipFree(q.device);
+      if (q.pinned) (void)hipHostFree(q.pinned);
+    }
     for (rt_scene::WfState* w : s->wf_states) {
       for (int l = 0; l <= MAX_DEPTH; l++) {
         if (w->wf_tasks[l]) (void)hipFree(w->wf_tasks[l]);
@@ -1059,12 +1105,39 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
   const uint64_t key = frame_key(dc, pm, depth, fast);
   rt_scene::WfPlan plan;  // a copy: the list may be reordered below
   bool planned = false;
-  for (const rt_scene::WfPlan& c : s->wf_plans)
-    if (c.key == key) {
-      plan = c;
+  for (size_t i = 0; i < s->wf_plans.size(); i++)
+    if (s->wf_plans[i].key == key) {
+      plan = s->wf_plans[i];
       planned = true;
+      // most recently rendered last: the oldest is the one forgotten, the newest the one
+      // estimates are taken from
+      s->wf_plans.erase(s->wf_plans.begin() + (long)i);
+      s->wf_plans.push_back(plan);
+      break;
     }
-  if (!planned) plan.key = key;
+  if (!planned) {
+    plan.key = key;
+    plan.depth = depth;
+    plan.fast = fast;
+    plan.n[0] = plan.front[0] = ntiles * (long long)(RT_TILE * RT_TILE);
+  }
+  // A frame never seen before normally costs a host read-back per level (below).  When the
+  // caller has asked for it (rt_render_device_estimated) and the scene has rendered a frame of
+  // the same size, depth and mode, the new frame is issued without any read-back instead: grids
+  // and buffers are sized from that frame's queue lengths plus a margin, the kernels take the
+  // true lengths from the device, and a level that outgrows its estimate marks the frame as
+  // incomplete (rt_estimated_frame_result tells; the caller renders it again the exact way).
+  constexpr int OVERFLOW_SLOT = 2 * (MAX_DEPTH + 1);
+  const rt_scene::WfPlan* estimate = nullptr;
+  if (!planned && s->allow_estimates && !stats)
+    for (const rt_scene::WfPlan& c : s->wf_plans)
+      if (c.levels > 0 && c.n[0] == ntiles * (long long)(RT_TILE * RT_TILE) && c.depth == depth && c.fast == fast)
+        estimate = &c;  // the most recent one wins
+  rt_scene::WfPlan estimate_copy;
+  if (estimate) {
+    estimate_copy = *estimate;
+    estimate = &estimate_copy;
+  }
   rt_scene::WfState* w = nullptr;
   for (rt_scene::WfState* c : s->wf_states)
     if (c->stream == st) w = c;
@@ -1115,7 +1188,9 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
 #define WF_LAUNCH(ST, PR, FA, CO)                                                                        \
   hipLaunchKernelGGL((k_wf_level<ST, PR, FA, CO>), grid, block, 0, st, s->d, dc, pm, tin, n, n_front, cap_in, \
                      nodes, static_cast<uint8_t*>(w->wf_live[l]), parents, d_f64, d_u8, tnext, cnt_next, cap,   \
-                     spawn ? 1 : 0, s->d_counters)
+                     spawn ? 1 : 0, s->d_counters,                                                              \
+                     (estimate && l > 0) ? w->wf_counts + 2 * l : (const unsigned int*)nullptr,                \
+                     w->wf_counts + OVERFLOW_SLOT)
 #define WF_LAUNCH2(ST, PR)              \
   do {                                  \
     if (fast && s->share_leaves)        \
@@ -1143,6 +1218,14 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
       if (l + 1 >= plan.levels) break;
       n = plan.n[l + 1];
       n_front = plan.front[l + 1];
+    } else if (estimate) {
+      // what the next launch and its buffers are sized for: a quarter more than the frame the
+      // estimate comes from, never more than two children per call of this level
+      const long long guess = (l + 1 < estimate->levels) ? estimate->n[l + 1] : 0;
+      n = std::min(2 * n, guess + guess / 4 + 16384);
+      n_front = n;  // the kernel reads both from the device
+      cap_in = cap;
+      continue;
     } else {
       HIP_TRY(hipMemcpyAsync(w->wf_counts_host + 2 * (l + 1), cnt_next, 2 * sizeof(unsigned int),
                              hipMemcpyDeviceToHost, st));
@@ -1155,7 +1238,17 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     cap_in = cap;
     if (n == 0) break;
   }
-  if (!planned) {
+  if (estimate) {
+    // the true queue lengths follow the frame to the host; rt_estimated_frame_result reads them
+    HIP_TRY(hipMemcpyAsync(w->wf_counts_host, w->wf_counts, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int),
+                           hipMemcpyDeviceToHost, st));
+    w->estimate_pending = true;
+    s->n_estimated++;
+    w->estimate_key = key;
+    w->estimate_depth = depth;
+    w->estimate_n0 = level_n[0];
+    s->estimated_fast = fast;
+  } else if (!planned) {
     plan.levels = levels;
     if (s->wf_plans.size() >= WF_MAX_PLANS) s->wf_plans.erase(s->wf_plans.begin());
     s->wf_plans.push_back(plan);
@@ -1169,10 +1262,14 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     const WfNode* nodes = static_cast<const WfNode*>(w->wf_nodes[l]);
     const uint8_t* live = static_cast<const uint8_t*>(w->wf_live[l]);
     if (l == 0)
-      hipLaunchKernelGGL(k_wf_combine<true>, grid, block, 0, st, nodes, live, m, (WfNode*)nullptr, d_f64, d_u8);
+      hipLaunchKernelGGL(k_wf_combine<true>, grid, block, 0, st, nodes, live, m, (WfNode*)nullptr, d_f64, d_u8,
+                         (const unsigned int*)nullptr,
+                         estimate ? w->wf_counts + OVERFLOW_SLOT : (const unsigned int*)nullptr);
     else
       hipLaunchKernelGGL(k_wf_combine<false>, grid, block, 0, st, nodes, live, m,
-                         static_cast<WfNode*>(w->wf_nodes[l - 1]), d_f64, d_u8);
+                         static_cast<WfNode*>(w->wf_nodes[l - 1]), d_f64, d_u8,
+                         estimate ? w->wf_counts + 2 * l : (const unsigned int*)nullptr,
+                         estimate ? w->wf_counts + OVERFLOW_SLOT : (const unsigned int*)nullptr);
     HIP_TRY(hipGetLastError());
     s->launches++;
   }
@@ -1208,6 +1305,7 @@ static int render_device_fixed(rt_scene* s, const rt_camera* cam, int depth, int
     // interleaved sub-shards of this call's tiles, each a wavefront frame of its own
     int split = s->frame_split;
     if (ntiles < 64 * (int64_t)split) split = 1;  // too small to be worth the extra launches
+    if (split > 1) s->allow_estimates = false;     // estimates are kept per caller stream
     if (split > 1) {
       while ((int)s->split_streams.size() < split - 1) {
         hipStream_t q = nullptr;
@@ -1255,6 +1353,86 @@ static int render_device_fixed(rt_scene* s, const rt_camera* cam, int depth, int
   return RT_OK;
 }
 
+}  // extern "C"
+
+// Internal to the library (csrc/rt_internal.h; used by the host mirror's camera sweeps).
+namespace rti {
+int render_device_estimated(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline,
+                            uint8_t* d_rgb_u8, void* hip_stream) {
+  if (!s) return fail(RT_ERR_ARG, "null argument");
+  s->allow_estimates = (pipeline == RT_PIPELINE_WAVEFRONT);
+  const int rc = rt_render_device(s, cam, depth, mode, pipeline, 0, 1, nullptr, d_rgb_u8, hip_stream, 0);
+  s->allow_estimates = false;
+  return rc;
+}
+
+int estimated_frame_result(rt_scene* s, void* hip_stream, int* complete) {
+  if (!s || !complete) return fail(RT_ERR_ARG, "null argument");
+  *complete = 1;
+  rt_scene::WfState* w = nullptr;
+  for (rt_scene::WfState* c : s->wf_states)
+    if (c->stream == static_cast<hipStream_t>(hip_stream)) w = c;
+  if (!w || !w->estimate_pending) return RT_OK;  // the last frame on this stream was issued the exact way
+  w->estimate_pending = false;
+  const unsigned int* h = w->wf_counts_host;
+  if (h[2 * (MAX_DEPTH + 1)] != 0u) {
+    *complete = 0;
+    s->n_estimate_missed++;
+    return RT_OK;
+  }
+  // the frame is good, and its queue lengths are known now: remember them like those of a
+  // frame rendered with read-backs
+  rt_scene::WfPlan plan;
+  plan.key = w->estimate_key;
+  plan.depth = w->estimate_depth;
+  plan.fast = s->estimated_fast;
+  plan.n[0] = plan.front[0] = w->estimate_n0;
+  plan.levels = 1;
+  for (int l = 1; l < w->estimate_depth; l++) {
+    plan.front[l] = h[2 * l];
+    plan.n[l] = (long long)h[2 * l] + (long long)h[2 * l + 1];
+    if (plan.n[l] == 0) break;
+    plan.levels = l + 1;
+  }
+  for (size_t i = 0; i < s->wf_plans.size(); i++)
+    if (s->wf_plans[i].key == plan.key) {
+      s->wf_plans.erase(s->wf_plans.begin() + (long)i);
+      break;
+    }
+  if (s->wf_plans.size() >= WF_MAX_PLANS) s->wf_plans.erase(s->wf_plans.begin());
+  s->wf_plans.push_back(plan);
+  return RT_OK;
+}
+int sweep_slot(rt_scene* s, int i, size_t bytes, void** stream, uint8_t** device, uint8_t** pinned) {
+  if (!s || !stream || !device || !pinned || i < 0 || i >= 8) return fail(RT_ERR_ARG, "bad sweep slot");
+  if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+  HIP_TRY(hipSetDevice(s->device));
+  if ((int)s->sweep_slots.size() <= i) s->sweep_slots.resize((size_t)i + 1);
+  rt_scene::SweepSlot& q = s->sweep_slots[i];
+  if (!q.stream) HIP_TRY(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
+  if (q.bytes < bytes) {
+    HIP_TRY(hipStreamSynchronize(q.stream));
+    if (q.device) (void)hipFree(q.device);
+    if (q.pinned) (void)hipHostFree(q.pinned);
+    q.device = q.pinned = nullptr;
+    q.bytes = 0;
+    HIP_TRY(hipMalloc((void**)&q.device, bytes));
+    HIP_TRY(hipHostMalloc((void**)&q.pinned, bytes, hipHostMallocDefault));
+    q.bytes = bytes;
+  }
+  *stream = q.stream;
+  *device = q.device;
+  *pinned = q.pinned;
+  return RT_OK;
+}
+
+void estimate_counters(const rt_scene* s, long long* issued, long long* missed) {
+  if (issued) *issued = s ? s->n_estimated : 0;
+  if (missed) *missed = s ? s->n_estimate_missed : 0;
+}
+}  // namespace rti
+
+extern "C" {
 // RT_PIPELINE_AUTO: the first time a frame (camera, shard, depth, mode) is seen it is rendered
 // once with each pipeline and timed with HIP events (both write the same bits); the faster
 // one is remembered for that frame.

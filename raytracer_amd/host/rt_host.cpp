@@ -4,6 +4,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include "../csrc/rt_internal.h"
+
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -719,27 +722,47 @@ int render_sequence_raw(rt_scene* scene, const rt_camera* cameras, int n, int de
   };
   std::vector<Slot> slots(F);
   bool hip_ok = true;
-  for (Slot& s : slots)
-    hip_ok = hip_ok && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
-             hipMalloc((void**)&s.device, largest) == hipSuccess &&
-             hipHostMalloc((void**)&s.pinned, largest, hipHostMallocDefault) == hipSuccess;
+  for (int i = 0; i < F; i++) {
+    Slot& s = slots[i];
+    void* q = nullptr;
+    hip_ok = hip_ok && rti::sweep_slot(scene, i, largest, &q, &s.device, &s.pinned) == RT_OK;
+    s.stream = static_cast<hipStream_t>(q);
+  }
   // waits for the frame a slot holds and hands its image to the caller
+  double t_sync = 0, t_copy = 0, t_issue = 0;  // host milliseconds, printed with RT_TRACE_SWEEP=1
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   auto collect = [&](Slot& s) {
     if (s.frame < 0) return true;
+    double ta = now();
     if (hipStreamSynchronize(s.stream) != hipSuccess) return false;
+    t_sync += now() - ta;
     const rt_camera& c = cameras[s.frame];
+    // a frame issued on an estimate of its ray-queue lengths that did not hold is rendered again
+    int complete = 1;
+    if (rti::estimated_frame_result(scene, s.stream, &complete) != RT_OK) return false;
+    if (!complete) {
+      if (rt_render_device(scene, &c, depth, mode, pipeline, 0, 1, nullptr, s.device, s.stream, 0) != RT_OK ||
+          hipMemcpyAsync(s.pinned, s.device, (size_t)c.hsize * c.vsize * 3, hipMemcpyDeviceToHost, s.stream) !=
+              hipSuccess ||
+          hipStreamSynchronize(s.stream) != hipSuccess)
+        return false;
+    }
+    double tb = now();
     std::memcpy(out[s.frame], s.pinned, (size_t)c.hsize * c.vsize * 3);
+    t_copy += now() - tb;
     s.frame = -1;
     return true;
   };
-  rc = hip_ok ? RT_OK : RT_ERR_HIP;
+  rc = hip_ok ? RT_OK : RT_ERR_HIP;  // (the slots' buffers and streams belong to the scene)
   for (int k = 0; k < n && rc == RT_OK; k++) {
     Slot& s = slots[k % F];
     if (!collect(s)) {
       rc = RT_ERR_HIP;
       break;
     }
-    rc = rt_render_device(scene, &cameras[k], depth, mode, pipeline, 0, 1, nullptr, s.device, s.stream, 0);
+    double tc = now();
+    rc = rti::render_device_estimated(scene, &cameras[k], depth, mode, pipeline, s.device, s.stream);
+    t_issue += now() - tc;
     if (rc != RT_OK) break;
     if (hipMemcpyAsync(s.pinned, s.device, (size_t)cameras[k].hsize * cameras[k].vsize * 3,
                        hipMemcpyDeviceToHost, s.stream) != hipSuccess) {
@@ -748,7 +771,8 @@ int render_sequence_raw(rt_scene* scene, const rt_camera* cameras, int n, int de
     }
     s.frame = k;
   }
-  // drain in frame order; on an error the streams are still waited for before anything is freed
+  // drain in frame order; on an error the streams are still waited for, so that nothing is in
+  // flight into the caller's or the scene's buffers when the call returns
   for (int j = 0; j < F; j++) {
     Slot& s = slots[(std::max(n, F) - F + j) % F];
     if (rc == RT_OK) {
@@ -757,11 +781,7 @@ int render_sequence_raw(rt_scene* scene, const rt_camera* cameras, int n, int de
       (void)hipStreamSynchronize(s.stream);
     }
   }
-  for (Slot& s : slots) {
-    if (s.pinned) (void)hipHostFree(s.pinned);
-    if (s.device) (void)hipFree(s.device);
-    if (s.stream) (void)hipStreamDestroy(s.stream);
-  }
+  if (getenv("RT_TRACE_SWEEP")) fprintf(stderr, "sweep n=%d F=%d: sync %.2f copy %.2f issue %.2f ms\n", n, F, t_sync, t_copy, t_issue);
   (void)hipSetDevice(previous);
   return rc;
 }

@@ -223,10 +223,11 @@ Canvas render(const Camera& camera, DeviceScene& scene, const RenderOptions& opt
 // tail of one frame's recursion level runs under the next frame and the copy back to the
 // host under both.  The frames are the ones render() returns for the same cameras.  Start
 // the process with GPU_MAX_HW_QUEUES=8 to give four frames in flight a hardware queue each.
-// A camera the scene has not rendered before is issued with one host read-back per recursion
-// level on the wavefront pipeline (the queue lengths size the next launch), which holds the
-// issuing thread until that frame is nearly done: a sweep of all-new cameras overlaps only its
-// copies, a loop that comes back to cameras it has seen (a turntable) overlaps fully.
+// A camera the scene has not rendered before normally costs one host read-back per recursion
+// level (the ray-queue lengths size the next launch).  A sweep issues it without them instead,
+// sized from the latest finished frame of the same size plus a quarter, and renders the frame
+// again the exact way if a queue outgrew that (csrc/rt_internal.h), so new cameras overlap too.
+// RT_TRACE_SWEEP=1 prints where the host's time went (waiting, copying, issuing).
 std::vector<Canvas> render_sequence(const std::vector<Camera>& cameras, DeviceScene& scene,
                                     const RenderOptions& opt = RenderOptions(), int inflight = 4);
 // The same over plain camera structs, into caller-provided images (out[k]: hsize*vsize*3

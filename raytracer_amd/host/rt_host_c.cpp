@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "rt_host.h"
+#include "../csrc/rt_internal.h"
 
 using namespace rt;
 
@@ -240,6 +241,18 @@ int rth_render_sequence(rth_world* w, const rt_camera* cameras, int n, int depth
     }
     return 0;
   });
+}
+
+int rth_sweep_counters(rth_world* w, int64_t* issued_on_estimate, int64_t* rendered_again) {
+  if (!w || !w->committed) {
+    g_herr = "world not committed";
+    return -1;
+  }
+  long long a = 0, b = 0;
+  rti::estimate_counters(w->device.handle(), &a, &b);
+  if (issued_on_estimate) *issued_on_estimate = a;
+  if (rendered_again) *rendered_again = b;
+  return 0;
 }
 
 int rth_write_ppm(const char* path, int width, int height, const uint8_t* rgb) {

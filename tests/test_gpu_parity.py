@@ -279,6 +279,62 @@ def test_camera_sweep_equals_single_frames(rt, O, pipeline):
     assert w.render_sequence([], pipeline=pipe) == []
 
 
+def turned(rt, base, angle, hsize=None, vsize=None):
+    """The camera `base` with its inverse transform turned about the y axis."""
+    import ctypes as C
+    rot = np.array([[math.cos(angle), 0, math.sin(angle), 0], [0, 1, 0, 0],
+                    [-math.sin(angle), 0, math.cos(angle), 0], [0, 0, 0, 1]], dtype=np.float64)
+    c = rt.CameraABI()
+    C.memmove(C.byref(c), C.byref(base), C.sizeof(c))
+    c.inv[:] = (rot @ np.array(list(base.inv), dtype=np.float64).reshape(4, 4)).reshape(16)
+    return c
+
+
+def test_sweep_of_new_cameras_is_issued_on_estimates(rt, O, pipeline):
+    """Cameras the scene has never rendered: after the first frame the sweep issues them without
+    read-backs, sized from the latest finished frame.  Frames equal the ones rendered alone —
+    also when an estimate does not hold (a frame of the empty sky followed by the glass pawn:
+    its ray queues outgrow the estimate and the frame is rendered again)."""
+    import ctypes as C
+    import torch
+    if pipeline != "wavefront":
+        pytest.skip("estimates belong to the wavefront pipeline")
+    w = rt.World.example("pawn", 640, 360)
+    base = w.camera_abi()
+    w.commit()
+    assert w.sweep_counters() == (0, 0)
+    sweep = [turned(rt, base, 0.01 * k) for k in range(1, 9)]
+    got = w.render_sequence(sweep, inflight=4)
+    issued, again = w.sweep_counters()
+    assert issued >= 4 and again == 0   # everything after the first frames in flight
+    # a frame that sees nothing (the camera turns its head straight up, away from floor and pawn)
+    # becomes the latest finished frame; the estimate it gives the next new camera cannot hold
+    buf = torch.zeros((360, 640, 3), dtype=torch.uint8, device="cuda")
+    blank = None
+    for pitch in (math.pi / 2, -math.pi / 2):
+        c = rt.CameraABI()
+        C.memmove(C.byref(c), C.byref(base), C.sizeof(c))
+        rx = np.array([[1, 0, 0, 0], [0, math.cos(pitch), -math.sin(pitch), 0],
+                       [0, math.sin(pitch), math.cos(pitch), 0], [0, 0, 0, 1]], dtype=np.float64)
+        c.inv[:] = (np.array(list(base.inv), dtype=np.float64).reshape(4, 4) @ rx).reshape(16)
+        w.render_device(d_u8=buf.data_ptr(), cam=c)
+        torch.cuda.synchronize()
+        if len(np.unique(buf.cpu().numpy())) == 1:
+            blank = c
+    assert blank is not None
+    w.render_device(d_u8=buf.data_ptr(), cam=blank)  # seen before: moves its queue lengths to the front
+    torch.cuda.synchronize()
+    back = turned(rt, base, 0.005)
+    got += w.render_sequence([back, back], inflight=1)
+    issued2, again2 = w.sweep_counters()
+    assert issued2 == issued + 1 and again2 == 1
+    for c, g in zip(sweep + [back, back], got):
+        w.render_device(d_u8=buf.data_ptr(), cam=c)
+        torch.cuda.synchronize()
+        assert np.array_equal(g, buf.cpu().numpy())
+    assert len(np.unique(got[-1])) > 50 and not np.array_equal(got[-1], got[0])
+
+
 # ---- random and adversarial scenes -------------------------------------------------------------
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_scenes(rt, O, seed):
