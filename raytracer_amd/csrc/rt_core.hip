@@ -1154,6 +1154,7 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
       w->stream = st;
     }
   }
+  w->estimate_pending = false;  // whatever an earlier frame on this stream left unread is void now
   if (!w->wf_counts) {
     HIP_TRY(hipMalloc(&w->wf_counts, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int)));
     HIP_TRY(hipHostMalloc(&w->wf_counts_host, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int)));
