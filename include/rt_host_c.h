@@ -66,7 +66,7 @@ rt_scene* rth_scene(rth_world*);
 int rth_render(rth_world*, int depth, int mode, int pipeline, double* out_rgb_f64,
                uint8_t* out_rgb_u8, rt_stats* stats);
 /* A camera sweep over the committed scene (no counterpart in the reference, which renders one
- * frame per process): frame k for cameras[k], up to `inflight` (1..8) frames at a time on
+ * frame per process): frame k for cameras[k], up to `inflight` (1..7) frames at a time on
  * streams of their own.  out_rgb_u8 receives the n images back to back (frame k:
  * hsize*vsize*3 bytes of cameras[k]); they equal what rth_render gives for each camera. */
 int rth_render_sequence(rth_world*, const rt_camera* cameras, int n, int depth, int mode,

@@ -706,7 +706,10 @@ int render_sequence_raw(rt_scene* scene, const rt_camera* cameras, int n, int de
   int rc = rt_scene_get_info(scene, &info);
   if (rc != RT_OK) return rc;
   if (n == 0) return RT_OK;
-  const int F = std::max(1, std::min(std::min(inflight, 8), n));
+  // F frames on the GPU at a time need F + 1 slots: the host copies the image of the frame that
+  // has just finished out of its slot while the frame that took its place runs in another.
+  const int F = std::max(1, std::min(std::min(inflight, 7), n));
+  const int S = F + 1;
   size_t largest = 0;
   for (int k = 0; k < n; k++) {
     if (cameras[k].hsize <= 0 || cameras[k].vsize <= 0 || !out[k]) return RT_ERR_ARG;
@@ -718,70 +721,79 @@ int render_sequence_raw(rt_scene* scene, const rt_camera* cameras, int n, int de
     hipStream_t stream = nullptr;
     uint8_t* device = nullptr;
     uint8_t* pinned = nullptr;
-    int frame = -1;  // the frame whose image is on its way into `pinned`
+    int frame = -1;  // the frame whose image is in, or on its way into, `pinned`
   };
-  std::vector<Slot> slots(F);
+  std::vector<Slot> slots(S);
   bool hip_ok = true;
-  for (int i = 0; i < F; i++) {
+  for (int i = 0; i < S; i++) {  // streams and buffers belong to the scene
     Slot& s = slots[i];
     void* q = nullptr;
     hip_ok = hip_ok && rti::sweep_slot(scene, i, largest, &q, &s.device, &s.pinned) == RT_OK;
     s.stream = static_cast<hipStream_t>(q);
   }
-  // waits for the frame a slot holds and hands its image to the caller
-  double t_sync = 0, t_copy = 0, t_issue = 0;  // host milliseconds, printed with RT_TRACE_SWEEP=1
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  auto collect = [&](Slot& s) {
+  double t_wait = 0, t_copy = 0, t_issue = 0;  // host milliseconds, printed with RT_TRACE_SWEEP=1
+  auto now = [] {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  };
+  auto bytes_of = [&](int frame) { return (size_t)cameras[frame].hsize * cameras[frame].vsize * 3; };
+  // waits until the slot's frame is in its pinned buffer
+  auto wait = [&](Slot& s) {
     if (s.frame < 0) return true;
-    double ta = now();
-    if (hipStreamSynchronize(s.stream) != hipSuccess) return false;
-    t_sync += now() - ta;
-    const rt_camera& c = cameras[s.frame];
+    const double t0 = now();
+    bool ok = hipStreamSynchronize(s.stream) == hipSuccess;
     // a frame issued on an estimate of its ray-queue lengths that did not hold is rendered again
     int complete = 1;
-    if (rti::estimated_frame_result(scene, s.stream, &complete) != RT_OK) return false;
-    if (!complete) {
-      if (rt_render_device(scene, &c, depth, mode, pipeline, 0, 1, nullptr, s.device, s.stream, 0) != RT_OK ||
-          hipMemcpyAsync(s.pinned, s.device, (size_t)c.hsize * c.vsize * 3, hipMemcpyDeviceToHost, s.stream) !=
-              hipSuccess ||
-          hipStreamSynchronize(s.stream) != hipSuccess)
-        return false;
-    }
-    double tb = now();
-    std::memcpy(out[s.frame], s.pinned, (size_t)c.hsize * c.vsize * 3);
-    t_copy += now() - tb;
-    s.frame = -1;
-    return true;
+    ok = ok && rti::estimated_frame_result(scene, s.stream, &complete) == RT_OK;
+    if (ok && !complete)
+      ok = rt_render_device(scene, &cameras[s.frame], depth, mode, pipeline, 0, 1, nullptr, s.device, s.stream, 0) ==
+               RT_OK &&
+           hipMemcpyAsync(s.pinned, s.device, bytes_of(s.frame), hipMemcpyDeviceToHost, s.stream) == hipSuccess &&
+           hipStreamSynchronize(s.stream) == hipSuccess;
+    t_wait += now() - t0;
+    return ok;
   };
-  rc = hip_ok ? RT_OK : RT_ERR_HIP;  // (the slots' buffers and streams belong to the scene)
+  // hands the slot's image to the caller
+  auto deliver = [&](Slot& s) {
+    if (s.frame < 0) return;
+    const double t0 = now();
+    std::memcpy(out[s.frame], s.pinned, bytes_of(s.frame));
+    t_copy += now() - t0;
+    s.frame = -1;
+  };
+  rc = hip_ok ? RT_OK : RT_ERR_HIP;
   for (int k = 0; k < n && rc == RT_OK; k++) {
-    Slot& s = slots[k % F];
-    if (!collect(s)) {
+    Slot& fresh = slots[k % S];         // delivered one iteration ago (or never used)
+    Slot& oldest = slots[(k + 1) % S];  // holds frame k - F
+    if (!wait(oldest)) {
       rc = RT_ERR_HIP;
       break;
     }
-    double tc = now();
-    rc = rti::render_device_estimated(scene, &cameras[k], depth, mode, pipeline, s.device, s.stream);
-    t_issue += now() - tc;
+    const double t0 = now();
+    rc = rti::render_device_estimated(scene, &cameras[k], depth, mode, pipeline, fresh.device, fresh.stream);
+    if (rc == RT_OK && hipMemcpyAsync(fresh.pinned, fresh.device, bytes_of(k), hipMemcpyDeviceToHost,
+                                      fresh.stream) != hipSuccess)
+      rc = RT_ERR_HIP;
+    t_issue += now() - t0;
     if (rc != RT_OK) break;
-    if (hipMemcpyAsync(s.pinned, s.device, (size_t)cameras[k].hsize * cameras[k].vsize * 3,
-                       hipMemcpyDeviceToHost, s.stream) != hipSuccess) {
-      rc = RT_ERR_HIP;
-      break;
-    }
-    s.frame = k;
+    fresh.frame = k;
+    deliver(oldest);  // under frame k and the F - 1 frames before it
   }
   // drain in frame order; on an error the streams are still waited for, so that nothing is in
   // flight into the caller's or the scene's buffers when the call returns
-  for (int j = 0; j < F; j++) {
-    Slot& s = slots[(std::max(n, F) - F + j) % F];
+  for (int j = 0; j < S; j++) {
+    Slot& s = slots[(n + j) % S];
     if (rc == RT_OK) {
-      if (!collect(s)) rc = RT_ERR_HIP;
+      if (wait(s))
+        deliver(s);
+      else
+        rc = RT_ERR_HIP;
     } else if (s.stream) {
       (void)hipStreamSynchronize(s.stream);
     }
   }
-  if (getenv("RT_TRACE_SWEEP")) fprintf(stderr, "sweep n=%d F=%d: sync %.2f copy %.2f issue %.2f ms\n", n, F, t_sync, t_copy, t_issue);
+  if (getenv("RT_TRACE_SWEEP"))
+    fprintf(stderr, "sweep of %d frames, %d in flight: host waited %.2f ms, copied %.2f ms, issued %.2f ms\n", n, F,
+            t_wait, t_copy, t_issue);
   (void)hipSetDevice(previous);
   return rc;
 }

@@ -218,7 +218,7 @@ Canvas render(const Camera& camera, const World& world, const RenderOptions& opt
 Canvas render(const Camera& camera, DeviceScene& scene, const RenderOptions& opt = RenderOptions());
 
 // A camera sweep over one committed scene (not in the reference, whose command line renders
-// one frame per process): frame k is rendered for cameras[k], up to `inflight` frames at a
+// one frame per process): frame k is rendered for cameras[k], up to `inflight` (1..7) frames at a
 // time on streams of their own, each with its own device and pinned host buffer, so the thin
 // tail of one frame's recursion level runs under the next frame and the copy back to the
 // host under both.  The frames are the ones render() returns for the same cameras.  Start

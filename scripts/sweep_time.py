@@ -23,7 +23,7 @@ def turned(angle):
 
 
 w.render_sequence([turned(0.0)] * 4, inflight=4)  # buffers of four streams sized
-n, first = 32, 1
+n, first = int(os.environ.get("N", "32")), 1
 for inflight in (1, 4):
     cams = [turned(0.002 * (first + k)) for k in range(n)]
     first += n
