@@ -2,17 +2,20 @@
 //   -t/--threads N   accepted for compatibility (main.rs:19-26); the GPU needs no thread count
 //   -e/--example X   "cover" (default) | "pawn" | "tea set"   (main.rs:27-35, 46-51)
 // Additions: --width/--height (override the example's size), --gpu N, --obj-dir DIR,
-// --out FILE (default canvas.ppm, main.rs:54; a name ending in .png is written as PNG), --stats.
+// --out FILE (default canvas.ppm, main.rs:54; a name ending in .png is written as PNG), --stats,
+// --sweep N (a turntable of N frames over one committed scene: FILE_000, FILE_001, ...).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "rt_host.h"
 
 int main(int argc, char** argv) {
   std::string example = "cover", out = "canvas.ppm", obj_dir = "./obj";
-  int width = 0, height = 0, gpu = -1;
+  int width = 0, height = 0, gpu = -1, sweep = 0;
   bool stats = false;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
@@ -37,6 +40,8 @@ int main(int argc, char** argv) {
       obj_dir = next();
     } else if (a == "--out") {
       out = next();
+    } else if (a == "--sweep") {
+      sweep = std::atoi(next());
     } else if (a == "--stats") {
       stats = true;
     } else {
@@ -54,9 +59,35 @@ int main(int argc, char** argv) {
     opt.device = gpu;
     rt_stats st;
     if (stats) opt.stats = &st;
+    const bool png = out.size() >= 4 && out.compare(out.size() - 4, 4, ".png") == 0;
+    if (sweep > 0) {
+      // a turntable: frame k sees the world turned by k * 2 pi / N about its y axis; the scene is
+      // committed once and the frames are rendered with four of them in flight
+      rt::DeviceScene ds;
+      if (!ds.commit(scene.second, gpu)) throw std::runtime_error("commit: " + ds.error());
+      std::vector<rt::Camera> cameras;
+      for (int k = 0; k < sweep; k++)
+        cameras.push_back(rt::Camera::new_with_transform(
+            scene.first.hsize, scene.first.vsize, scene.first.field_of_view,
+            scene.first.transform * rt::Matrix::rotation_y(k * 6.283185307179586 / sweep)));
+      std::printf("Rendering %d frames on GPU %d\n", sweep, gpu < 0 ? 0 : gpu);
+      std::vector<rt::Canvas> frames = rt::render_sequence(cameras, ds, opt, 4);
+      const size_t dot = out.rfind('.');
+      const std::string stem = dot == std::string::npos ? out : out.substr(0, dot);
+      const std::string ext = dot == std::string::npos ? "" : out.substr(dot);
+      for (int k = 0; k < sweep; k++) {
+        char num[16];
+        std::snprintf(num, sizeof num, "_%03d", k);
+        const std::string name = stem + num + ext;
+        if (!(png ? frames[k].write_to_png(name) : frames[k].write_to_ppm(name))) {
+          std::fprintf(stderr, "could not create file %s\n", name.c_str());
+          return 1;
+        }
+      }
+      return 0;
+    }
     std::printf("Rendering image on GPU %d\n", gpu < 0 ? 0 : gpu);
     rt::Canvas image = rt::render(scene.first, scene.second, opt);
-    const bool png = out.size() >= 4 && out.compare(out.size() - 4, 4, ".png") == 0;
     if (!(png ? image.write_to_png(out) : image.write_to_ppm(out))) {
       std::fprintf(stderr, "could not create file %s\n", out.c_str());
       return 1;

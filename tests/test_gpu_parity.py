@@ -242,6 +242,14 @@ def test_cli_writes_the_reference_ppm(rt, O, tmp_path, pipeline):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert np.array_equal(O.read_png_rgb8(str(png)), ou8)
+    # a turntable of three frames over one committed scene: frame 0 is the example's own view
+    r = subprocess.run([os.path.join(repo, "raytracer_amd", "rt_cli"), "-e", "pawn", "--width", "160", "--height", "90",
+                        "--obj-dir", os.path.join(repo, "assets", "obj"), "--out", str(tmp_path / "turn.png"),
+                        "--sweep", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    turn = [O.read_png_rgb8(str(tmp_path / f"turn_{k:03d}.png")) for k in range(3)]
+    assert np.array_equal(turn[0], ou8)
+    assert not np.array_equal(turn[1], ou8) and not np.array_equal(turn[2], turn[1])
 
 
 def test_camera_sweep_equals_single_frames(rt, O, pipeline):
