@@ -202,6 +202,26 @@ int64_t rt_shard_tiles(int hsize, int vsize, int tile_first, int tile_step);
 int rt_detile_u8(const uint8_t* d_tiles, int nshards, int64_t tiles_per_shard, int hsize,
                  int vsize, uint8_t* d_image, void* hip_stream);
 
+/* ---- a render entry point that allocates nothing --------------------------------------- */
+/* No counterpart in the reference.  For callers that cannot allocate device memory while they
+ * render: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * Same frame and same output layout as rt_render_device on the wavefront pipeline (the same
+ * kernels), but the ray queues, result nodes and counters live in ONE fixed device array of
+ * RT_NOALLOC_SCRATCH_BYTES that each GPU the library runs on holds until the process ends,
+ * and the call issues no hipMalloc/hipFree, no read-back and no synchronisation: it only
+ * enqueues work on hip_stream.  The shard is rendered in batches of rt_noalloc_max_tiles(depth)
+ * tiles, each sized for the worst case (every call spawning two rays), so no queue can overflow.
+ * Limits: 1 <= depth <= 8; at most RT_NOALLOC_MAX_TILES tiles per call (RT_ERR_UNSUPPORTED with
+ * a message otherwise: pass a larger tile_step and call once per shard).  All calls on one GPU
+ * share the array: calls that overlap on one GPU (different streams, different scenes) race;
+ * calls on one stream, or ordered by events, do not. */
+#define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
+#define RT_NOALLOC_MAX_TILES 8192
+int rt_render_device_noalloc(rt_scene*, const rt_camera*, int depth, int mode, int tile_first,
+                             int tile_step, double* d_rgb_f64, uint8_t* d_rgb_u8, void* hip_stream);
+/* tiles per internal batch at this depth (19 at depth 5), or -1 for a depth out of range */
+int64_t rt_noalloc_max_tiles(int depth);
+
 /* ---- single-ray queries (known-answer tests of the device functions) ------------------ */
 /* Traces n rays (origins/directions: n x 3 doubles, host) through the committed scene.
  * out: n x 32 doubles, per ray:

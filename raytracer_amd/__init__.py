@@ -147,6 +147,10 @@ def lib():
     L.rt_render_device.argtypes = [vp, C.POINTER(CameraABI), C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, vp, vp, vp, C.c_int]
     L.rt_render_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.rt_render_device_noalloc.argtypes = [vp, C.POINTER(CameraABI), C.c_int, C.c_int, C.c_int, C.c_int,
+                                           vp, vp, vp]
+    L.rt_noalloc_max_tiles.argtypes = [C.c_int]
+    L.rt_noalloc_max_tiles.restype = C.c_int64
     L.rt_shard_tiles.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.rt_shard_tiles.restype = C.c_int64
     L.rt_detile_u8.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp]
@@ -348,6 +352,17 @@ class World:
         if rc != 0:
             raise RtError(f"rt_render_device: {self.L.rt_last_error().decode()}")
 
+    def render_device_noalloc(self, d_u8=None, d_f64=None, stream=None, depth=5, mode=MODE_F64_PARITY,
+                              tile_first=0, tile_step=1, cam=None):
+        """rt_render_device_noalloc: the wavefront frame out of the library's fixed device array
+        (no allocation, no synchronisation); same outputs as render_device."""
+        cam = cam or self.camera_abi()
+        rc = self.L.rt_render_device_noalloc(self.scene, C.byref(cam), depth, mode, tile_first, tile_step,
+                                             C.c_void_p(d_f64 or 0), C.c_void_p(d_u8 or 0),
+                                             C.c_void_p(stream or 0))
+        if rc != 0:
+            raise RtError(f"rt_render_device_noalloc: {self.L.rt_last_error().decode()}")
+
     def stats(self):
         st = Stats()
         if self.L.rt_render_stats(self.scene, C.byref(st)) != 0:
@@ -363,6 +378,14 @@ class World:
         if rc != 0:
             raise RtError(f"rt_trace_rays: {self.L.rt_last_error().decode()}")
         return out
+
+
+NOALLOC_MAX_TILES = 8192
+NOALLOC_SCRATCH_BYTES = 64 << 20
+
+
+def noalloc_max_tiles(depth):
+    return lib().rt_noalloc_max_tiles(depth)
 
 
 def shard_tiles(hsize, vsize, tile_first, tile_step):

@@ -671,6 +671,8 @@ static int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
   return RT_OK;
 }
 
+static int scratch_for_device(int device, unsigned char** out);
+
 // ---------------------------------------------------------------------------------------
 extern "C" {
 #ifdef RT_SECTION_TIMES
@@ -836,6 +838,13 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   auto t0 = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(device));
   s->device = device;
+  {
+    // the address of this device's copy of the fixed array rt_render_device_noalloc works in:
+    // looked up here, where allocating is allowed, so that the entry point itself never has to
+    unsigned char* unused = nullptr;
+    int rc_scratch = scratch_for_device(device, &unused);
+    if (rc_scratch) return rc_scratch;
+  }
 
   std::string why;
   std::vector<DGroup> groups(s->groups.size());
@@ -1351,6 +1360,143 @@ static int render_device_fixed(rt_scene* s, const rt_camera* cam, int depth, int
   }
   HIP_TRY(hipEventRecord(s->ev1, st));
   s->timing_pending = true;
+  return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// rt_render_device_noalloc: the wavefront frame with its ray queues, result nodes and counters
+// in one fixed device array instead of buffers from hipMalloc.  Every GPU the library runs on
+// holds its own copy of the array at its own address (found once per device with
+// hipGetSymbolAddress, with that device current; in host code the array's NAME is not a device
+// address).  Calls on one GPU share the array: a call clears the counters it needs at its
+// start, and calls that overlap on one GPU (different streams) race.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static unsigned char* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+
+// The device's copy of `scratch`; the device must be current.
+static int scratch_for_device(int device, unsigned char** out) {
+  if (device < 0 || device >= NOALLOC_MAX_DEVICES) return fail(RT_ERR_ARG, "device index out of range");
+  if (!g_scratch_ptr[device]) {
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(RT_ERR_HIP, "hipGetSymbolAddress returned no address for the scratch array");
+    g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+  }
+  *out = g_scratch_ptr[device];
+  return RT_OK;
+}
+
+// Layout of one batch of `px` primary rays at `depth` in the scratch array, sized for the worst
+// case (every call spawns a reflected and a refracted ray: level l holds at most px << l calls),
+// so that no level can outgrow its queue.  Returns the bytes needed.
+struct NoallocLayout {
+  size_t counts, tasks[MAX_DEPTH + 1], nodes[MAX_DEPTH + 1], live[MAX_DEPTH + 1];
+  long long cap[MAX_DEPTH + 1];
+};
+static size_t noalloc_layout(long long px, int depth, NoallocLayout& L) {
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t off = 0;
+  L.counts = off;
+  off = up(off + 2 * (MAX_DEPTH + 2) * sizeof(unsigned int));
+  for (int l = 0; l < depth; l++) {
+    const bool spawn = l + 1 < depth;
+    L.cap[l] = px << l;
+    L.live[l] = off;
+    off = up(off + (size_t)L.cap[l]);
+    L.nodes[l] = off;
+    if (spawn) off = up(off + (size_t)L.cap[l] * sizeof(WfNode));
+    L.tasks[l + 1] = off;
+    if (spawn) off = up(off + 2 * (size_t)L.cap[l] * sizeof(WfTask));
+  }
+  L.tasks[0] = 0;
+  return off;
+}
+
+int64_t rt_noalloc_max_tiles(int depth) {
+  if (depth < 0 || depth > MAX_DEPTH) return -1;
+  NoallocLayout L;
+  int64_t best = 0;
+  for (int64_t t = 1; t <= RT_NOALLOC_MAX_TILES; t++) {
+    if (noalloc_layout(t * (RT_TILE * RT_TILE), depth, L) > (size_t)RT_NOALLOC_SCRATCH_BYTES) break;
+    best = t;
+  }
+  return best;
+}
+
+int rt_render_device_noalloc(rt_scene* s, const rt_camera* cam, int depth, int mode, int tile_first,
+                             int tile_step, double* d_rgb_f64, uint8_t* d_rgb_u8, void* hip_stream) {
+  if (!s || !cam) return fail(RT_ERR_ARG, "null argument");
+  if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+  if (mode != RT_MODE_F64_PARITY && mode != RT_MODE_F32_FAST) return fail(RT_ERR_ARG, "unknown mode");
+  if (depth < 1 || depth > MAX_DEPTH) return fail(RT_ERR_ARG, "depth out of range (1..8)");
+  if (!d_rgb_f64 && !d_rgb_u8) return fail(RT_ERR_ARG, "no output buffer");
+  DCamera dc;
+  int rc = camera_to_device(cam, dc);
+  if (rc) return rc;
+  const int64_t ntiles = rt_shard_tiles(cam->hsize, cam->vsize, tile_first, tile_step);
+  if (ntiles < 0) return fail(RT_ERR_ARG, "bad tile shard");
+  if (ntiles > RT_NOALLOC_MAX_TILES)
+    return fail(RT_ERR_UNSUPPORTED,
+                "rt_render_device_noalloc: this shard has " + std::to_string(ntiles) + " tiles, the maximum per call is " +
+                    std::to_string(RT_NOALLOC_MAX_TILES) + " (render fewer tiles per call: a larger tile_step)");
+  const int64_t batch_tiles = rt_noalloc_max_tiles(depth);
+  if (batch_tiles < 1) return fail(RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: depth too large for the scratch array");
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  HIP_TRY(hipSetDevice(s->device));
+  unsigned char* base = nullptr;
+  if ((rc = scratch_for_device(s->device, &base))) return rc;
+  const bool fast = mode == RT_MODE_F32_FAST;
+  constexpr int OVERFLOW_SLOT = 2 * (MAX_DEPTH + 1);
+  for (int64_t k0 = 0; k0 < ntiles; k0 += batch_tiles) {
+    const int64_t bt = std::min<int64_t>(batch_tiles, ntiles - k0);
+    NoallocLayout L;
+    noalloc_layout(bt * (RT_TILE * RT_TILE), depth, L);
+    PixelMap pm = pixel_map(cam, tile_first, tile_step);
+    pm.tile_first = (int)(tile_first + k0 * tile_step);  // local tile k of this batch = shard tile k0 + k
+    pm.out_k_mul = 1;
+    pm.out_k_add = (int)k0;
+    unsigned int* counts = reinterpret_cast<unsigned int*>(base + L.counts);
+    HIP_TRY(hipMemsetAsync(counts, 0, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int), st));
+    for (int l = 0; l < depth; l++) {
+      const bool spawn = l + 1 < depth;
+      const long long n = L.cap[l];
+      dim3 grid((unsigned)((n + WF_BLOCK - 1) / WF_BLOCK)), block(WF_BLOCK);
+      const WfTask* tin = reinterpret_cast<const WfTask*>(base + L.tasks[l]);
+      WfNode* nodes = reinterpret_cast<WfNode*>(base + L.nodes[l]);
+      uint8_t* live = base + L.live[l];
+      WfNode* parents = l > 0 ? reinterpret_cast<WfNode*>(base + L.nodes[l - 1]) : nullptr;
+      WfTask* tnext = spawn ? reinterpret_cast<WfTask*>(base + L.tasks[l + 1]) : nullptr;
+      const unsigned int cap_in = l > 0 ? (unsigned int)(2 * L.cap[l - 1]) : 0u;
+      const unsigned int cap = spawn ? (unsigned int)(2 * n) : 0u;
+      const unsigned int* counts_in = l > 0 ? counts + 2 * l : nullptr;
+#define NA_LAUNCH(PR, FA)                                                                                   \
+  hipLaunchKernelGGL((k_wf_level<false, PR, FA, true>), grid, block, 0, st, s->d, dc, pm, tin, n, n, cap_in, \
+                     nodes, live, parents, d_rgb_f64, d_rgb_u8, tnext, counts + 2 * (l + 1), cap,            \
+                     spawn ? 1 : 0, s->d_counters, counts_in, counts + OVERFLOW_SLOT)
+      if (l == 0) {
+        if (fast) NA_LAUNCH(true, true); else NA_LAUNCH(true, false);
+      } else {
+        if (fast) NA_LAUNCH(false, true); else NA_LAUNCH(false, false);
+      }
+#undef NA_LAUNCH
+      HIP_TRY(hipGetLastError());
+    }
+    for (int l = depth - 2; l >= 0; l--) {  // the levels that spawned: back up the recursion tree
+      const long long m = L.cap[l];
+      dim3 block(256), grid((unsigned)((m + 255) / 256));
+      const WfNode* nodes = reinterpret_cast<const WfNode*>(base + L.nodes[l]);
+      const uint8_t* live = base + L.live[l];
+      if (l == 0)
+        hipLaunchKernelGGL(k_wf_combine<true>, grid, block, 0, st, nodes, live, m, (WfNode*)nullptr, d_rgb_f64,
+                           d_rgb_u8, (const unsigned int*)nullptr, (const unsigned int*)nullptr);
+      else
+        hipLaunchKernelGGL(k_wf_combine<false>, grid, block, 0, st, nodes, live, m,
+                           reinterpret_cast<WfNode*>(base + L.nodes[l - 1]), d_rgb_f64, d_rgb_u8,
+                           (const unsigned int*)(counts + 2 * l), (const unsigned int*)nullptr);
+      HIP_TRY(hipGetLastError());
+    }
+  }
   return RT_OK;
 }
 
