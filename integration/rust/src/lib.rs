@@ -161,7 +161,16 @@ impl SceneBuilder {
     /// `p1..p3`: xyz per triangle in face order; normals empty for flat triangles.
     pub fn mesh(&mut self, group: i32, material: i32, p1: &[f64], p2: &[f64], p3: &[f64],
                 n1: &[f64], n2: &[f64], n3: &[f64], smooth: &[u8]) -> i32 {
+        assert!(p1.len() % 3 == 0, "p1 must hold xyz per triangle");
+        assert!(p2.len() == p1.len() && p3.len() == p1.len(), "p1, p2, p3 must have one length");
         let ntris = (p1.len() / 3) as i64;
+        let has_n = !(n1.is_empty() && n2.is_empty() && n3.is_empty());
+        if has_n {
+            assert!(n1.len() == p1.len() && n2.len() == p1.len() && n3.len() == p1.len(),
+                    "n1, n2, n3 must all be empty or as long as p1");
+        }
+        assert!(smooth.is_empty() || (has_n && smooth.len() as i64 == ntris),
+                "smooth needs normals and one byte per triangle");
         let opt = |v: &[f64]| if v.is_empty() { std::ptr::null() } else { v.as_ptr() };
         let m = RtMesh {
             group, material, ntris,

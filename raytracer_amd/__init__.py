@@ -419,6 +419,8 @@ def write_ppm(path, rgb):
 def mat_inverse(m):
     a = np.ascontiguousarray(np.asarray(m, dtype=np.float64))
     n = a.shape[0]
+    if a.ndim != 2 or a.shape[1] != n:
+        raise RtError("matrix must be square")
     flat = a.reshape(-1).copy()
     out = np.zeros(n * n)
     if lib().rth_mat_inverse(_dp(flat), n, _dp(out)) != 0:
@@ -429,6 +431,8 @@ def mat_inverse(m):
 def mat_determinant(m):
     a = np.ascontiguousarray(np.asarray(m, dtype=np.float64))
     flat = a.reshape(-1).copy()
+    if a.ndim != 2 or a.shape[0] != a.shape[1] or not 2 <= a.shape[0] <= 4:
+        raise RtError("matrix size must be 2, 3 or 4")
     return lib().rth_mat_determinant(_dp(flat), a.shape[0])
 
 

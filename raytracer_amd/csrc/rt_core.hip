@@ -81,10 +81,16 @@ struct rt_scene {
     uint64_t estimate_key = 0;
     int estimate_depth = 0;
     long long estimate_n0 = 0;
+    bool estimate_fast = false;
+    hipEvent_t done = nullptr;  // recorded behind the last frame issued with this set
+    uint64_t last_use = 0;      // tick of that frame: the set used longest ago is the one handed on
   };
+  uint64_t wf_tick = 0;
+  // Results of estimated frames whose buffer set was handed to another stream before the caller
+  // asked (estimated_frame_result): stream -> complete
+  std::vector<std::pair<hipStream_t, int>> orphan_results;
   // set around a call by rt_render_device_estimated: unseen frames may be issued on an estimate
   bool allow_estimates = false;
-  bool estimated_fast = false;
   // camera sweeps (rti::sweep_slot): streams and image buffers of the scene's own, grow only
   struct SweepSlot {
     hipStream_t stream = nullptr;
@@ -698,7 +704,7 @@ rt_scene* rt_scene_create(void) { return new rt_scene(); }
 
 void rt_scene_destroy(rt_scene* s) {
   if (!s) return;
-  if (s->committed) {
+  if (s->device >= 0) {  // also after a commit that failed half way: what it uploaded is freed
     int cur = 0;
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(s->device);
@@ -723,6 +729,7 @@ void rt_scene_destroy(rt_scene* s) {
       }
       if (w->wf_counts) (void)hipFree(w->wf_counts);
       if (w->wf_counts_host) (void)hipHostFree(w->wf_counts_host);
+      if (w->done) (void)hipEventDestroy(w->done);
       delete w;
     }
     (void)hipSetDevice(cur);
@@ -1108,6 +1115,40 @@ static uint64_t frame_key(const DCamera& dc, const PixelMap& pm, int depth, bool
   return h ? h : 1;
 }
 
+// Verdict on the frame last issued with set `w` on an estimate, once its counters have reached
+// the host (the caller has synchronised): *complete = 0 if a ray queue outgrew its estimate.
+// A frame that is good leaves its true queue lengths behind as a plan.
+static void resolve_estimate(rt_scene* s, rt_scene::WfState* w, int* complete) {
+  *complete = 1;
+  if (!w->estimate_pending) return;
+  w->estimate_pending = false;
+  const unsigned int* h = w->wf_counts_host;
+  if (h[2 * (MAX_DEPTH + 1)] != 0u) {
+    *complete = 0;
+    s->n_estimate_missed++;
+    return;
+  }
+  rt_scene::WfPlan plan;
+  plan.key = w->estimate_key;
+  plan.depth = w->estimate_depth;
+  plan.fast = w->estimate_fast;
+  plan.n[0] = plan.front[0] = w->estimate_n0;
+  plan.levels = 1;
+  for (int l = 1; l < w->estimate_depth; l++) {
+    plan.front[l] = h[2 * l];
+    plan.n[l] = (long long)h[2 * l] + (long long)h[2 * l + 1];
+    if (plan.n[l] == 0) break;
+    plan.levels = l + 1;
+  }
+  for (size_t i = 0; i < s->wf_plans.size(); i++)
+    if (s->wf_plans[i].key == plan.key) {
+      s->wf_plans.erase(s->wf_plans.begin() + (long)i);
+      break;
+    }
+  if (s->wf_plans.size() >= WF_MAX_PLANS) s->wf_plans.erase(s->wf_plans.begin());
+  s->wf_plans.push_back(plan);
+}
+
 static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, int64_t ntiles,
                             int depth, double* d_f64, uint8_t* d_u8, hipStream_t st, bool stats,
                             bool fast) {
@@ -1147,23 +1188,40 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     estimate_copy = *estimate;
     estimate = &estimate_copy;
   }
+  // a new frame on this stream: whatever verdict an earlier one left unasked is void now
+  for (size_t i = s->orphan_results.size(); i-- > 0;)
+    if (s->orphan_results[i].first == st) s->orphan_results.erase(s->orphan_results.begin() + (long)i);
   rt_scene::WfState* w = nullptr;
   for (rt_scene::WfState* c : s->wf_states)
     if (c->stream == st) w = c;
   if (!w) {
-    constexpr size_t WF_MAX_STREAMS = 8;
+    // 8 sweep slots of the scene's own plus as many caller streams before sets are shared
+    constexpr size_t WF_MAX_STREAMS = 16;
     if (s->wf_states.size() < WF_MAX_STREAMS) {
       w = new rt_scene::WfState;
       w->stream = st;
       s->wf_states.push_back(w);
     } else {
-      // more streams than buffer sets: order this one behind the set's previous user
-      w = s->wf_states.back();
-      HIP_TRY(hipStreamSynchronize(w->stream));
+      // More streams than buffer sets: this one takes over the set used longest ago, ordered
+      // behind that set's last frame through the event recorded after it (the stream it ran on
+      // may be gone by now; its event is not).  A frame issued on an estimate that nobody has
+      // asked about yet is resolved first, so its verdict is not lost with the set.
+      for (rt_scene::WfState* c : s->wf_states)
+        if (!w || (c->estimate_pending ? 1 : 0) < (w->estimate_pending ? 1 : 0) ||
+            ((c->estimate_pending == w->estimate_pending) && c->last_use < w->last_use))
+          w = c;
+      if (w->done) HIP_TRY(hipEventSynchronize(w->done));
+      if (w->estimate_pending) {
+        int complete = 1;
+        resolve_estimate(s, w, &complete);
+        s->orphan_results.push_back({w->stream, complete});
+      }
       w->stream = st;
     }
   }
-  w->estimate_pending = false;  // whatever an earlier frame on this stream left unread is void now
+  if (!w->done) HIP_TRY(hipEventCreateWithFlags(&w->done, hipEventDisableTiming));
+  w->last_use = ++s->wf_tick;
+  w->estimate_pending = false;  // a new frame on this stream: an unasked verdict of an earlier one is void
   if (!w->wf_counts) {
     HIP_TRY(hipMalloc(&w->wf_counts, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int)));
     HIP_TRY(hipHostMalloc(&w->wf_counts_host, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int)));
@@ -1257,7 +1315,7 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     w->estimate_key = key;
     w->estimate_depth = depth;
     w->estimate_n0 = level_n[0];
-    s->estimated_fast = fast;
+    w->estimate_fast = fast;
   } else if (!planned) {
     plan.levels = levels;
     if (s->wf_plans.size() >= WF_MAX_PLANS) s->wf_plans.erase(s->wf_plans.begin());
@@ -1283,6 +1341,7 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     HIP_TRY(hipGetLastError());
     s->launches++;
   }
+  HIP_TRY(hipEventRecord(w->done, st));
   return RT_OK;
 }
 
@@ -1516,38 +1575,20 @@ int render_device_estimated(rt_scene* s, const rt_camera* cam, int depth, int mo
 int estimated_frame_result(rt_scene* s, void* hip_stream, int* complete) {
   if (!s || !complete) return fail(RT_ERR_ARG, "null argument");
   *complete = 1;
+  const hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  // the frame's buffer set may have moved on to another stream (or frame) meanwhile: its verdict
+  // was taken then
+  for (size_t i = 0; i < s->orphan_results.size(); i++)
+    if (s->orphan_results[i].first == st) {
+      *complete = s->orphan_results[i].second;
+      s->orphan_results.erase(s->orphan_results.begin() + (long)i);
+      return RT_OK;
+    }
   rt_scene::WfState* w = nullptr;
   for (rt_scene::WfState* c : s->wf_states)
-    if (c->stream == static_cast<hipStream_t>(hip_stream)) w = c;
+    if (c->stream == st) w = c;
   if (!w || !w->estimate_pending) return RT_OK;  // the last frame on this stream was issued the exact way
-  w->estimate_pending = false;
-  const unsigned int* h = w->wf_counts_host;
-  if (h[2 * (MAX_DEPTH + 1)] != 0u) {
-    *complete = 0;
-    s->n_estimate_missed++;
-    return RT_OK;
-  }
-  // the frame is good, and its queue lengths are known now: remember them like those of a
-  // frame rendered with read-backs
-  rt_scene::WfPlan plan;
-  plan.key = w->estimate_key;
-  plan.depth = w->estimate_depth;
-  plan.fast = s->estimated_fast;
-  plan.n[0] = plan.front[0] = w->estimate_n0;
-  plan.levels = 1;
-  for (int l = 1; l < w->estimate_depth; l++) {
-    plan.front[l] = h[2 * l];
-    plan.n[l] = (long long)h[2 * l] + (long long)h[2 * l + 1];
-    if (plan.n[l] == 0) break;
-    plan.levels = l + 1;
-  }
-  for (size_t i = 0; i < s->wf_plans.size(); i++)
-    if (s->wf_plans[i].key == plan.key) {
-      s->wf_plans.erase(s->wf_plans.begin() + (long)i);
-      break;
-    }
-  if (s->wf_plans.size() >= WF_MAX_PLANS) s->wf_plans.erase(s->wf_plans.begin());
-  s->wf_plans.push_back(plan);
+  resolve_estimate(s, w, complete);
   return RT_OK;
 }
 int sweep_slot(rt_scene* s, int i, size_t bytes, void** stream, uint8_t** device, uint8_t** pinned) {

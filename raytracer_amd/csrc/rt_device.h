@@ -332,6 +332,27 @@ __device__ __forceinline__ bool box_may_hit(const DPrimBox& B, const BoxRay& r, 
   return !(tin > tout + 1e-9 * (fabs(tin) + fabs(tout)));
 }
 
+// A cube whose box the ray misses may still be hit by the reference: check_axis (cube.rs:54-60)
+// treats an object-space direction component below EPSILON as parallel and ignores the drift
+// along that axis, so a near-parallel ray that geometrically leaves the slab by up to
+// EPSILON * t is still given (tmin, tmax).  Such rays are never culled.
+__device__ __forceinline__ bool cube_cull_unsafe(const DScene& S, const DPrim& P, const Ray& r) {
+  V3 d = r.d;
+  if (P.parent >= 0) {
+    const DGroup& G = S.groups[P.parent];
+    for (int k = 0; k < G.nchain; k++) d = xf_vector(S.groups[G.chain[k]].inv, d);
+  }
+  d = xf_vector(P.inv, d);
+  return fabs(d.x) < EPS || fabs(d.y) < EPS || fabs(d.z) < EPS;
+}
+// true when primitive p can be skipped for intersections inside (tlo, thi)
+__device__ __forceinline__ bool prim_culled(const DScene& S, int p, const Ray& ray, const BoxRay& br, double tlo,
+                                            double thi) {
+  if (box_may_hit(S.prim_boxes[p], br, tlo, thi)) return false;
+  const DPrim& P = S.prims[p];
+  return !(P.kind == 2 && cube_cull_unsafe(S, P, ray));
+}
+
 // ---------------------------------------------------------------------------------------
 // BVH traversal.  The hierarchy only culls; what a triangle test returns is the f64
 // arithmetic of moller_trumbore() above, bit for bit.  Culling itself runs in f32 against
@@ -1024,7 +1045,7 @@ __device__ inline bool trace_closest(const DScene& S, const Ray& ray, HitRec& h,
   int prim = -1;
   const BoxRay br = make_box_ray(ray);
   for (int p = 0; p < S.n_prims; p++) {
-    if (!box_may_hit(S.prim_boxes[p], br, 0.0, q.hi)) continue;
+    if (prim_culled(S, p, ray, br, 0.0, q.hi)) continue;
     const DPrim& P = S.prims[p];
     Ray lr = ray_to_prim(S, P, ray);
     double ts[4];
@@ -1071,7 +1092,7 @@ __device__ inline bool trace_any(const DScene& S, const Ray& ray, double distanc
                                  TravStack& st) {
   const BoxRay br = make_box_ray(ray);
   for (int p = 0; p < S.n_prims; p++) {
-    if (!box_may_hit(S.prim_boxes[p], br, 0.0, distance)) continue;
+    if (prim_culled(S, p, ray, br, 0.0, distance)) continue;
     const DPrim& P = S.prims[p];
     Ray lr = ray_to_prim(S, P, ray);
     double ts[4];
@@ -1139,7 +1160,7 @@ __device__ inline bool trace_closest_coop(const DScene& S, const Ray& ray, bool 
   if (enabled) {
     const BoxRay br = make_box_ray(ray);
     for (int p = 0; p < S.n_prims; p++) {
-      if (!box_may_hit(S.prim_boxes[p], br, 0.0, q.hi)) continue;
+      if (prim_culled(S, p, ray, br, 0.0, q.hi)) continue;
       const DPrim& P = S.prims[p];
       Ray lr = ray_to_prim(S, P, ray);
       double ts[4];
@@ -1184,7 +1205,7 @@ __device__ inline bool trace_any_coop(const DScene& S, const Ray& ray, double di
   if (enabled) {
     const BoxRay br = make_box_ray(ray);
     for (int p = 0; p < S.n_prims && !found; p++) {
-      if (!box_may_hit(S.prim_boxes[p], br, 0.0, distance)) continue;
+      if (prim_culled(S, p, ray, br, 0.0, distance)) continue;
       const DPrim& P = S.prims[p];
       Ray lr = ray_to_prim(S, P, ray);
       double ts[4];
@@ -1268,7 +1289,7 @@ __device__ inline void containers_from(const DScene& S, const Ray& ray, const Hi
   const BoxRay br = make_box_ray(ray);
   for (int p = 0; p < S.n_prims; p++) {
     // only entries below K count, and they have t <= K.t
-    if (!box_may_hit(S.prim_boxes[p], br, -RT_INF, K.t)) continue;
+    if (prim_culled(S, p, ray, br, -RT_INF, K.t)) continue;
     const DPrim& P = S.prims[p];
     Ray lr = ray_to_prim(S, P, ray);
     double ts[4];

@@ -40,6 +40,7 @@ Matrix Matrix::identity(int size) {
   return r;
 }
 Matrix Matrix::from_rows(const double* v, int size) {
+  if (size < 1 || size > 4) throw std::invalid_argument("Matrix::from_rows: size must be 1..4");
   Matrix r;
   r.size = size;
   for (int i = 0; i < size; i++)

@@ -1,6 +1,7 @@
 // rt_host_c.cpp — C wrappers of the host mirror (include/rt_host_c.h).
 #include "../../include/rt_host_c.h"
 
+#include <limits>
 #include <cstring>
 #include <exception>
 #include <string>
@@ -96,6 +97,10 @@ int rth_load_example(rth_world* w, const char* name, const char* obj_dir, int hs
 
 int rth_add_light(rth_world* w, const double intensity[3], const double position[3]) {
   if (!w || !intensity || !position) return -1;
+  if (w->committed) {
+    g_herr = "world already committed";
+    return -1;
+  }
   w->world.light_sources.push_back(
       {{intensity[0], intensity[1], intensity[2]}, Tuple::point(position[0], position[1], position[2])});
   return (int)w->world.light_sources.size() - 1;
@@ -104,6 +109,10 @@ int rth_add_light(rth_world* w, const double intensity[3], const double position
 int rth_add_shape(rth_world* w, int parent, int kind, const double* transform16,
                   const rth_material* material, double minimum, double maximum, int closed) {
   if (!w) return -1;
+  if (w->committed) {
+    g_herr = "world already committed";
+    return -1;
+  }
   return guarded([&] {
     std::optional<Matrix> t = to_matrix(transform16);
     std::unique_ptr<Shape> s;
@@ -137,6 +146,10 @@ int rth_add_shape(rth_world* w, int parent, int kind, const double* transform16,
 
 int rth_add_triangle(rth_world* w, int parent, const double* p, const double* n) {
   if (!w || !p) return -1;
+  if (w->committed) {
+    g_herr = "world already committed";
+    return -1;
+  }
   return guarded([&] {
     Tuple p1 = Tuple::point(p[0], p[1], p[2]), p2 = Tuple::point(p[3], p[4], p[5]),
           p3 = Tuple::point(p[6], p[7], p[8]);
@@ -153,6 +166,10 @@ int rth_add_triangle(rth_world* w, int parent, const double* p, const double* n)
 int rth_add_obj(rth_world* w, int parent, const char* obj_text, const double* transform16,
                 const rth_material* material) {
   if (!w || !obj_text) return -1;
+  if (w->committed) {
+    g_herr = "world already committed";
+    return -1;
+  }
   return guarded([&] {
     std::optional<Material> m;
     if (material) m = to_material(material);
@@ -274,12 +291,22 @@ int rth_write_png(const char* path, int width, int height, const uint8_t* rgb) {
 }
 
 int rth_mat_inverse(const double* m, int size, double* out) {
+  if (!m || !out || size < 2 || size > 4) {
+    g_herr = "matrix size must be 2, 3 or 4";
+    return -1;
+  }
   return guarded([&] {
     Matrix::from_rows(m, size).inverse().to_rows(out);
     return 0;
   });
 }
-double rth_mat_determinant(const double* m, int size) { return Matrix::from_rows(m, size).determinant(); }
+double rth_mat_determinant(const double* m, int size) {
+  if (!m || size < 2 || size > 4) {
+    g_herr = "matrix size must be 2, 3 or 4";
+    return std::numeric_limits<double>::quiet_NaN();
+  }
+  return Matrix::from_rows(m, size).determinant();
+}
 void rth_mat_mul(const double* a16, const double* b16, double* out16) {
   (Matrix::from_rows(a16, 4) * Matrix::from_rows(b16, 4)).to_rows(out16);
 }

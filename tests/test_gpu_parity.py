@@ -346,6 +346,52 @@ def test_sweep_of_new_cameras_is_issued_on_estimates(rt, O, pipeline):
     assert len(np.unique(got[-1])) > 50 and not np.array_equal(got[-1], got[0])
 
 
+def test_estimated_sweep_after_many_caller_streams(rt, pipeline):
+    """More streams than the scene keeps ray-queue sets for: twelve caller streams render first,
+    then a sweep of new cameras with seven frames in flight (eight slots of the scene's own) has
+    to take sets over.  A set whose frame was issued on an estimate must not lose its verdict:
+    the sweep starts behind a frame of empty sky, so the first estimates cannot hold, and every
+    frame must still equal the one rendered alone."""
+    import ctypes as C
+    import os
+    import torch
+    if pipeline != "wavefront":
+        pytest.skip("estimates belong to the wavefront pipeline")
+    if os.environ.get("RT_FRAME_SPLIT", "1") != "1":
+        pytest.skip("a frame split over internal streams is always issued the exact way")
+    w = rt.World.example("pawn", 320, 180)
+    base = w.camera_abi()
+    w.commit()
+    buf = torch.zeros((180, 320, 3), dtype=torch.uint8, device="cuda")
+    streams = [torch.cuda.Stream() for _ in range(12)]
+    for st in streams:
+        w.render_device(d_u8=buf.data_ptr(), stream=st.cuda_stream)
+        torch.cuda.synchronize()
+    blank = None
+    for pitch in (math.pi / 2, -math.pi / 2):
+        c = rt.CameraABI()
+        C.memmove(C.byref(c), C.byref(base), C.sizeof(c))
+        rx = np.array([[1, 0, 0, 0], [0, math.cos(pitch), -math.sin(pitch), 0],
+                       [0, math.sin(pitch), math.cos(pitch), 0], [0, 0, 0, 1]], dtype=np.float64)
+        c.inv[:] = (np.array(list(base.inv), dtype=np.float64).reshape(4, 4) @ rx).reshape(16)
+        w.render_device(d_u8=buf.data_ptr(), cam=c)  # the null stream: a thirteenth set
+        torch.cuda.synchronize()
+        if len(np.unique(buf.cpu().numpy())) == 1:
+            blank = c
+    assert blank is not None
+    w.render_device(d_u8=buf.data_ptr(), cam=blank)
+    torch.cuda.synchronize()
+    sweep = [turned(rt, base, 0.02 * k) for k in range(1, 17)]
+    got = w.render_sequence(sweep, inflight=7)
+    issued, again = w.sweep_counters()
+    assert issued >= 8 and again >= 1
+    for c, g in zip(sweep, got):
+        w.render_device(d_u8=buf.data_ptr(), cam=c)
+        torch.cuda.synchronize()
+        assert np.array_equal(g, buf.cpu().numpy())
+    assert len(np.unique(got[0])) > 50
+
+
 # ---- random and adversarial scenes -------------------------------------------------------------
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_scenes(rt, O, seed):
@@ -518,6 +564,37 @@ def test_many_random_rays_bitwise(rt, O):
     assert hits > n // 2
 
 
+def test_kat_cube_near_parallel_ray_is_not_culled(rt, O):
+    """cube.rs:54-60 treats |direction| < EPSILON on an axis as parallel and ignores the drift
+    along it: a ray that starts just inside the x slab and leaves it by 9e-4 before it reaches
+    the cube is still a hit in the reference.  The world-space box in front of the cube test must
+    not cull it."""
+    def b(T, M, X):
+        T.add_shape(scenes.CUBE, None, M(a=(1, 0, 0)))
+        T.add_light((1, 1, 1), (-10, 10, -10))
+        T.set_camera(8, 8, 1.0, X.view_transform((0, 0, -5), (0, 0, 0), (0, 1, 0)))
+    w, s = build_both(rt, O, b)
+    for o, d in (((1 - 1e-9, -100.0, 0.0), (9e-6, 1.0, 0.0)), ((0.0, 1 - 1e-9, -50.0), (0.0, 9e-6, 1.0)),
+                 ((-(1 - 1e-9), 0.3, 40.0), (-9e-6, 0.0, -1.0))):
+        r, oi = trace(w, o, d), s.trace_info(o, d)
+        assert oi["hit"] and r["hit"], (o, d)
+        assert r["t"] == oi["t"] and np.array_equal(r["normalv"], oi["normalv"])
+        assert r["shadowed"] == s.is_shadowed(oi["over_point"])
+
+
+def test_host_wrappers_refuse_bad_calls(rt):
+    with pytest.raises(rt.RtError):
+        rt.mat_inverse(np.eye(5))
+    with pytest.raises(rt.RtError):
+        rt.mat_determinant(np.eye(1))
+    w = rt.World.example("cover", 16, 16).commit()
+    with pytest.raises(rt.RtError):
+        w.add_shape(scenes.SPHERE)
+    with pytest.raises(rt.RtError):
+        w.add_triangle([0, 1, 0, -1, 0, 0, 1, 0, 0])
+    assert w.add_light((1, 1, 1), (0, 0, 0)) < 0
+
+
 # ---- edge cases --------------------------------------------------------------------------------
 def test_empty_world_and_no_lights(rt, O):
     w = rt.World()
@@ -576,6 +653,38 @@ def test_tile_shards_stitch_to_the_full_image(rt, nshards):
     rt.detile_u8(tiles.data_ptr(), nshards, per, hs, vs, img.data_ptr(), stream)
     torch.cuda.synchronize()
     assert np.array_equal(img.cpu().numpy(), full)
+
+
+def test_pawn_8k_tile_shards(rt, O, pipeline):
+    """The 7680x4320 pawn frame as the multi-GPU decomposition cuts it (240 x 135 tiles dealt
+    round-robin to 8 and to 2 shards), every shard rendered on this one GPU, stitched with
+    rt_detile_u8: byte-equal to the unsharded frame and equal to the oracle on a pixel sample."""
+    import torch
+    if pipeline != "wavefront":
+        pytest.skip("the shards of the 8K frame are rendered with the pipeline the bench uses")
+    hs, vs = 7680, 4320
+    w = rt.World.example("pawn", hs, vs).commit()
+    stream = torch.cuda.current_stream().cuda_stream
+    full = torch.zeros((vs, hs, 3), dtype=torch.uint8, device="cuda")
+    w.render_device(d_u8=full.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    assert len(torch.unique(full[::16, ::16])) > 50
+    for nshards in (8, 2):
+        per = max(rt.shard_tiles(hs, vs, s, nshards) for s in range(nshards))
+        assert sum(rt.shard_tiles(hs, vs, s, nshards) for s in range(nshards)) == 240 * 135
+        tiles = torch.zeros((nshards, per * rt.TILE * rt.TILE * 3), dtype=torch.uint8, device="cuda")
+        for s in range(nshards):
+            w.render_device(d_u8=tiles[s].data_ptr(), stream=stream, tile_first=s, tile_step=nshards)
+        img = torch.zeros((vs, hs, 3), dtype=torch.uint8, device="cuda")
+        rt.detile_u8(tiles.data_ptr(), nshards, per, hs, vs, img.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert torch.equal(img, full), nshards
+        del tiles, img
+    sc = O.Scene.example("pawn", hs, vs).use_bvh()
+    rng = np.random.default_rng(12)
+    xs, ys = rng.integers(0, hs, 30000).astype(np.int32), rng.integers(0, vs, 30000).astype(np.int32)
+    _, ou8, _ = sc.render_pixels(xs, ys)
+    assert np.array_equal(full.cpu().numpy()[ys, xs], ou8)
 
 
 @pytest.mark.parametrize("split", [2, 3])
