@@ -71,6 +71,11 @@ struct rt_scene {
     void* wf_tasks[MAX_DEPTH + 1] = {};
     void* wf_nodes[MAX_DEPTH + 1] = {};
     void* wf_live[MAX_DEPTH + 1] = {};  // one byte per node: 1 = children will add to it
+    void* wf_keys[MAX_DEPTH + 1] = {};  // coherence sort: key per task slot / task slot per sorted position
+    void* wf_perm[MAX_DEPTH + 1] = {};
+    size_t wf_keys_cap[MAX_DEPTH + 1] = {};
+    size_t wf_perm_cap[MAX_DEPTH + 1] = {};
+    unsigned int* wf_hist = nullptr;  // SORT_BINS counters (zero between uses) + SORT_BINS cursors
     size_t wf_task_cap[MAX_DEPTH + 1] = {};
     size_t wf_node_cap[MAX_DEPTH + 1] = {};
     size_t wf_live_cap[MAX_DEPTH + 1] = {};
@@ -121,8 +126,14 @@ struct rt_scene {
   // A wavefront frame is rendered as frame_split interleaved tile shards on streams of the
   // scene's own, forked from and joined to the caller's stream, so that the thin tail of one
   // shard's level runs under another shard's work (RT_FRAME_SPLIT, 1 = off).
-  int frame_split = 1;
+  int frame_split = 0;  // 0: decided per frame (see render_device_fixed)
+  // coherence sort of the ray queues (see SortGrid): grid over the world-space bounds of the
+  // geometry; queues of level >= sort_min_level are sorted (RT_SORT_RAYS=0 switches it off)
+  double sort_lo[3] = {0, 0, 0}, sort_inv_cell[3] = {0, 0, 0};
+  bool sort_enabled = false;
+  int sort_min_level = 1;
   std::vector<hipStream_t> split_streams;
+  std::vector<std::pair<hipStream_t, hipEvent_t>> caller_done;  // per caller stream: behind its last frame
   std::vector<hipEvent_t> split_joined;
   hipEvent_t split_fork = nullptr;
 };
@@ -220,6 +231,35 @@ static DPrimBox world_box_of(const rt_scene* s, const rt_primitive& P) {
     B.hi[a] = whi[a] + pad;
   }
   return B;
+}
+
+// World-space bounds of an object-space box under group g (corners through the inverse of the
+// chain of inverse transforms); false when the chain cannot be inverted.
+static bool world_bounds_of_box(const rt_scene* s, int g, const double* lo, const double* hi, double* wlo,
+                                double* whi) {
+  double total[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (; g >= 0; g = s->groups[g].parent) {
+    double t[16];
+    mat4_mul(total, s->groups[g].inv, t);
+    std::memcpy(total, t, sizeof total);
+  }
+  double fwd[16];
+  if (!affine_inverse(total, fwd)) return false;
+  for (int a = 0; a < 3; a++) {
+    wlo[a] = std::numeric_limits<double>::infinity();
+    whi[a] = -std::numeric_limits<double>::infinity();
+  }
+  for (int k = 0; k < 8; k++) {
+    double p[3] = {(k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2]};
+    for (int a = 0; a < 3; a++) {
+      double v = fwd[4 * a] * p[0] + fwd[4 * a + 1] * p[1] + fwd[4 * a + 2] * p[2] + fwd[4 * a + 3];
+      wlo[a] = std::fmin(wlo[a], v);
+      whi[a] = std::fmax(whi[a], v);
+    }
+  }
+  for (int a = 0; a < 3; a++)
+    if (!std::isfinite(wlo[a]) || !std::isfinite(whi[a])) return false;
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -419,12 +459,145 @@ __device__ __forceinline__ void combine_node(const WfNode& N, WfNode* parents, d
   }
 }
 
+// Coherence sort of a level's ray queue.  The calls of level >= 1 arrive in the order the
+// parents' atomics happened to run; a wave of 64 consecutive tasks then holds rays that start
+// all over the scene and walk unrelated subtrees (the fan-out of world.rs:78-114).  Every task
+// gets a key when it is appended — ray kind, direction octant, Morton code of the origin's cell
+// in a grid over the world-space bounds of the geometry — and a counting sort over the keys
+// (histogram in the emitting kernel, one scan block, one scatter pass) yields the order the
+// next level's kernel takes its tasks in.  The order changes which lanes share a wave, never a
+// result: every call writes into its own node and its parent's slot.
+#ifndef RT_SORT_CELL_BITS
+#define RT_SORT_CELL_BITS 4  // per axis
+#endif
+#ifndef RT_SORT_DIR_BITS
+#define RT_SORT_DIR_BITS 3  // 3: direction octant; 7: cube-map face and a 4 x 4 grid on it
+#endif
+constexpr int SORT_CELL_BITS = RT_SORT_CELL_BITS;
+constexpr int SORT_DIR_BITS = RT_SORT_DIR_BITS;
+constexpr int SORT_KEY_BITS = 3 * SORT_CELL_BITS + SORT_DIR_BITS + 1;  // kind, direction, cell
+constexpr unsigned int SORT_BINS = 1u << SORT_KEY_BITS;
+static_assert(SORT_BINS >= 1024 && SORT_KEY_BITS <= 20, "the scan block handles 2^10 .. 2^20 bins");
+struct SortGrid {
+  double lo[3], inv_cell[3];
+  int enabled;
+};
+__device__ __forceinline__ unsigned int spread3(unsigned int v) {  // bits of v to every third position
+  unsigned int r = 0;
+#pragma unroll
+  for (int b = 0; b < SORT_CELL_BITS; b++) r |= ((v >> b) & 1u) << (3 * b);
+  return r;
+}
+// refracted rays (inside glass: the longest walks) get the low keys and are dispatched first
+__device__ __forceinline__ unsigned int sort_key(const SortGrid& g, const Ray& r, unsigned int reflected) {
+  constexpr double top = (double)((1 << SORT_CELL_BITS) - 1);
+  const double cx = fmin(fmax((r.o.x - g.lo[0]) * g.inv_cell[0], 0.0), top);
+  const double cy = fmin(fmax((r.o.y - g.lo[1]) * g.inv_cell[1], 0.0), top);
+  const double cz = fmin(fmax((r.o.z - g.lo[2]) * g.inv_cell[2], 0.0), top);
+  const unsigned int cell = spread3((unsigned int)(int)cx) | (spread3((unsigned int)(int)cy) << 1) |
+                            (spread3((unsigned int)(int)cz) << 2);
+  unsigned int dir;
+  if (SORT_DIR_BITS == 3) {
+    dir = (r.d.x < 0.0 ? 1u : 0u) | (r.d.y < 0.0 ? 2u : 0u) | (r.d.z < 0.0 ? 4u : 0u);
+  } else {
+    const float dx = (float)r.d.x, dy = (float)r.d.y, dz = (float)r.d.z;
+    const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+    float m, u, v;
+    unsigned int face;
+    if (ax >= ay && ax >= az) {
+      m = ax; u = dy; v = dz; face = dx < 0.f ? 1u : 0u;
+    } else if (ay >= az) {
+      m = ay; u = dx; v = dz; face = dy < 0.f ? 3u : 2u;
+    } else {
+      m = az; u = dx; v = dy; face = dz < 0.f ? 5u : 4u;
+    }
+    const float s = 2.0f / fmaxf(m, 1e-30f);  // u/m in [-1, 1] -> [0, 4)
+    const int qu = min(max((int)(u * s + 2.0f), 0), 3), qv = min(max((int)(v * s + 2.0f), 0), 3);
+    dir = (face << 4) | ((unsigned int)qu << 2) | (unsigned int)qv;
+  }
+  return (reflected << (SORT_KEY_BITS - 1)) | (dir << (3 * SORT_CELL_BITS)) | cell;
+}
+// One histogram update per distinct key among the wave's active lanes instead of one per lane:
+// rays of one wave mostly share a key, and atomics of many lanes on one address serialise.
+// (The loop runs over a mask of lanes still to serve, which every iteration shrinks; a loop
+// whose only exit is `key == readfirstlane(key)` has no per-lane progress and is compiled away.)
+__device__ __forceinline__ void hist_add(unsigned int* hist, unsigned int key) {
+  unsigned long long todo = __ballot(1);
+  const int lane = (int)__lane_id();
+  while (todo) {  // uniform over the lanes that came in
+    const int leader = __ffsll((long long)todo) - 1;
+    const unsigned int k = (unsigned int)__builtin_amdgcn_readlane((int)key, leader);
+    const unsigned long long same = __ballot(key == k);
+    if (lane == leader) atomicAdd(&hist[k], (unsigned int)__popcll(same));
+    todo &= ~same;
+  }
+}
+// exclusive prefix sum of the histogram into `cursor` (one block); leaves the histogram zeroed
+__global__ void __launch_bounds__(1024) k_wf_sort_scan(unsigned int* hist, unsigned int* cursor) {
+  constexpr int PER = SORT_BINS / 1024;
+  __shared__ unsigned int part[1024];
+  const int t = threadIdx.x;
+  unsigned int local[PER];
+  unsigned int sum = 0;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    local[k] = hist[t * PER + k];
+    hist[t * PER + k] = 0u;
+    sum += local[k];
+  }
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    unsigned int v = (t >= off) ? part[t - off] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  unsigned int run = part[t] - sum;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    cursor[t * PER + k] = run;
+    run += local[k];
+  }
+}
+// position in key order -> slot of the task in the queue (reflected rays fill it from the front,
+// refracted rays from the back); the order inside one bin is whatever the atomics give
+__global__ void k_wf_sort_scatter(const unsigned int* keys, long long n, long long n_front, unsigned int cap,
+                                  unsigned int* cursor, unsigned int* perm, const unsigned int* counts_in) {
+  if (counts_in) {  // a frame issued on an estimate: the true lengths are on the device
+    const long long have_front = counts_in[0], have = have_front + counts_in[1];
+    if (have > n) return;  // the level kernel raises the overflow flag
+    n = have;
+    n_front = have_front;
+  }
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned int slot = (i < n_front) ? (unsigned int)i : cap - 1u - (unsigned int)(i - n_front);
+  const unsigned int key = keys[slot];
+  // one atomic per distinct key among the wave's lanes; each lane takes its rank inside the group
+  unsigned long long todo = __ballot(1);
+  const int lane = (int)__lane_id();
+  unsigned int pos = 0;
+  while (todo) {  // uniform over the lanes that came in
+    const int leader = __ffsll((long long)todo) - 1;
+    const unsigned int k = (unsigned int)__builtin_amdgcn_readlane((int)key, leader);
+    const unsigned long long same = __ballot(key == k);
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(&cursor[k], (unsigned int)__popcll(same));
+    base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+    if (key == k) pos = base + (unsigned int)__popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  perm[pos] = slot;
+}
+
 // Fills the level's result node and appends the child rays to the next level's queue:
 // reflected rays from the front, refracted rays from the back (world.rs:78-114).
 template <bool STATS>
 __device__ __forceinline__ bool emit_result(const ShadeOut& so, const C3& surface, WfNode& nd, long long i,
                                             WfTask* next, unsigned int* next_count, unsigned int next_cap,
-                                            int spawn, Counters& cnt) {
+                                            int spawn, Counters& cnt, const SortGrid& grid,
+                                            unsigned int* next_keys, unsigned int* hist) {
   nd.surface[0] = surface.r;
   nd.surface[1] = surface.g;
   nd.surface[2] = surface.b;
@@ -448,6 +621,11 @@ __device__ __forceinline__ bool emit_result(const ShadeOut& so, const C3& surfac
         T.coef = so.reflective;
         T.parent = (int32_t)i;
         T.slot = 0;
+        if (next_keys) {
+          const unsigned int key = sort_key(grid, so.reflect_ray, 1u);
+          next_keys[idx] = key;
+          hist_add(hist, key);
+        }
       }
     } else if (STATS) {
       cnt.depth0_skipped++;
@@ -467,6 +645,11 @@ __device__ __forceinline__ bool emit_result(const ShadeOut& so, const C3& surfac
         T.coef = so.transparency;
         T.parent = (int32_t)i;
         T.slot = 1;
+        if (next_keys) {
+          const unsigned int key = sort_key(grid, so.refract_ray, 0u);
+          next_keys[next_cap - 1 - idx] = key;
+          hist_add(hist, key);
+        }
       }
     } else if (STATS) {
       cnt.depth0_skipped++;
@@ -514,7 +697,8 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
            unsigned int cap, WfNode* nodes, uint8_t* live, WfNode* parents, double* out_f64, uint8_t* out_u8,
            WfTask* next,
            unsigned int* next_count, unsigned int next_cap, int spawn, unsigned long long* counters,
-           const unsigned int* counts_in, unsigned int* overflow) {
+           const unsigned int* counts_in, unsigned int* overflow, SortGrid grid, const unsigned int* perm,
+           unsigned int* next_keys, unsigned int* hist) {
   static_assert(WF_BLOCK == 64, "the traversal stack is laid out for 64-lane blocks");
   RT_TRAV_STACK_COOP(st, S);
 #ifdef RT_SECTION_TIMES
@@ -557,11 +741,12 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
     }
     active = i < n;
     if (active) {
-      // Reflected rays fill the queue from the front, refracted rays from the back.  The
-      // refracted ones (inside glass: the longest walks) take the lowest indices, so they are
-      // dispatched first and the level's tail is made of cheap rays.
+      // In key order when the queue has been sorted.  Otherwise: reflected rays fill the queue
+      // from the front, refracted rays from the back, and the refracted ones (inside glass: the
+      // longest walks) take the lowest indices, so they are dispatched first and the level's
+      // tail is made of cheap rays.
       const long long n_back = n - n_front;
-      const WfTask& T = tasks[i < n_back ? (long long)cap - 1 - i : i - n_back];
+      const WfTask& T = tasks[perm ? (long long)perm[i] : (i < n_back ? (long long)cap - 1 - i : i - n_back)];
       ray = {v3(T.o[0], T.o[1], T.o[2]), v3(T.d[0], T.d[1], T.d[2])};
       nd.parent = T.parent;
       nd.coef = T.coef;
@@ -581,6 +766,27 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
     RT_SECTION(0);
     const bool hit = trace_closest_coop<STATS, FAST>(S, ray, active, h, cnt, st);
     RT_SECTION(1);
+    // The container query comes first: it needs only the ray and the hit, so nothing of the
+    // shading state is alive (and parked in scratch) while it walks.
+    int mat_index = 0;
+    if (hit) mat_index = h.prim >= 0 ? S.prims[h.prim].material : S.meshes[h.mesh].material;
+    const bool need = hit && needs_n1_n2(S.mats[mat_index]);
+    double n1 = 1.0, n2 = 1.0;
+    {
+      Key K{0.0, 0u, 0}, tb{0.0, 0u, 0};
+      int tm = -1;
+      if (need) {
+        if (STATS) cnt.pred_queries++;
+        K = trigger_key(S, ray, h);
+      }
+      bool tf = false;
+      RT_SECTION(2);
+      if (S.n_meshes > 0)
+        tf = tri_predecessor_coop<STATS, FAST>(S, ray, predecessor_bound(K), h.prim >= 0 ? -1 : h.tri, need, tb,
+                                               tm, cnt, st);
+      RT_SECTION(4);
+      if (need) containers_from<STATS>(S, ray, h, K, S.mats[mat_index].refractive_index, tf, tb, tm, n1, n2, cnt);
+    }
     Prep pr;
     pr.mat_index = 0;
     C3 surface = {0.0, 0.0, 0.0};
@@ -603,26 +809,14 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
       RT_SECTION(3);
       if (hit) add_light(S.mats[pr.mat_index], L, pc, sr.d, pr.normal, vneg(ray.d), shadow, surface);
     }
-    const bool need = hit && needs_n1_n2(S.mats[pr.mat_index]);
-    Key K{0.0, 0u, 0}, tb{0.0, 0u, 0};
-    int tm = -1;
-    if (need) {
-      if (STATS) cnt.pred_queries++;
-      K = trigger_key(S, ray, h);
-    }
-    bool tf = false;
-    RT_SECTION(2);
-    if (S.n_meshes > 0)
-      tf = tri_predecessor_coop<STATS, FAST>(S, ray, predecessor_bound(K), h.prim >= 0 ? -1 : h.tri, need, tb,
-                                             tm, cnt, st);
-    RT_SECTION(4);
     if (hit) {
       const DMaterial& M = S.mats[pr.mat_index];
-      double n1 = 1.0, n2 = 1.0;
-      if (need) containers_from<STATS>(S, ray, h, K, M.refractive_index, tf, tb, tm, n1, n2, cnt);
       ShadeOut so;
+      // the same expression prepare_hit evaluated (intersect.rs:184): computed again here so that
+      // the point need not stay in registers through the shadow queries
+      pr.under = vsub(ray_at(ray, h.t), vmul(pr.normal, EPS));
       finish_optics(M, ray, pr, n1, n2, so);
-      has_children = emit_result<STATS>(so, surface, nd, i, next, next_count, next_cap, spawn, cnt);
+      has_children = emit_result<STATS>(so, surface, nd, i, next, next_count, next_cap, spawn, cnt, grid, next_keys, hist);
     }
   } else {
     if (active) {
@@ -630,7 +824,7 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
       if (trace_closest<STATS, FAST>(S, ray, h, cnt, st)) {
         ShadeOut so;
         shade_hit_local<STATS, FAST>(S, ray, h, so, cnt, st);
-        has_children = emit_result<STATS>(so, so.surface, nd, i, next, next_count, next_cap, spawn, cnt);
+        has_children = emit_result<STATS>(so, so.surface, nd, i, next, next_count, next_cap, spawn, cnt, grid, next_keys, hist);
       }
     }
   }
@@ -716,6 +910,7 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->split_fork) (void)hipEventDestroy(s->split_fork);
     for (hipEvent_t e : s->split_joined) (void)hipEventDestroy(e);
     for (hipStream_t q : s->split_streams) (void)hipStreamDestroy(q);
+    for (auto& c : s->caller_done) (void)hipEventDestroy(c.second);
     for (rt_scene::SweepSlot& q : s->sweep_slots) {
       if (q.stream) (void)hipStreamDestroy(q.stream);
       if (q.device) (void)hipFree(q.device);
@@ -726,8 +921,11 @@ void rt_scene_destroy(rt_scene* s) {
         if (w->wf_tasks[l]) (void)hipFree(w->wf_tasks[l]);
         if (w->wf_nodes[l]) (void)hipFree(w->wf_nodes[l]);
         if (w->wf_live[l]) (void)hipFree(w->wf_live[l]);
+        if (w->wf_keys[l]) (void)hipFree(w->wf_keys[l]);
+        if (w->wf_perm[l]) (void)hipFree(w->wf_perm[l]);
       }
       if (w->wf_counts) (void)hipFree(w->wf_counts);
+      if (w->wf_hist) (void)hipFree(w->wf_hist);
       if (w->wf_counts_host) (void)hipHostFree(w->wf_counts_host);
       if (w->done) (void)hipEventDestroy(w->done);
       delete w;
@@ -999,6 +1197,42 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     }
   }
 
+  {
+    // grid of the coherence sort: over the meshes' world-space bounds, or, in a scene without
+    // meshes, over the finite boxes of the closed-form shapes
+    const double inf = std::numeric_limits<double>::infinity();
+    double glo[3] = {inf, inf, inf}, ghi[3] = {-inf, -inf, -inf};
+    bool any = false;
+    for (size_t mi = 0; mi < meshes.size(); mi++) {
+      if (meshes[mi].ntris == 0) continue;
+      double wlo[3], whi[3];
+      if (!world_bounds_of_box(s, meshes[mi].group, meshes[mi].lo, meshes[mi].hi, wlo, whi)) continue;
+      for (int a = 0; a < 3; a++) {
+        glo[a] = std::fmin(glo[a], wlo[a]);
+        ghi[a] = std::fmax(ghi[a], whi[a]);
+      }
+      any = true;
+    }
+    if (!any)
+      for (const DPrimBox& B : prim_boxes) {
+        bool finite = true;
+        for (int a = 0; a < 3; a++) finite = finite && std::isfinite(B.lo[a]) && std::isfinite(B.hi[a]);
+        if (!finite) continue;
+        for (int a = 0; a < 3; a++) {
+          glo[a] = std::fmin(glo[a], B.lo[a]);
+          ghi[a] = std::fmax(ghi[a], B.hi[a]);
+        }
+        any = true;
+      }
+    s->sort_enabled = any;
+    for (int a = 0; a < 3 && any; a++) {
+      const double ext = ghi[a] - glo[a];
+      s->sort_lo[a] = glo[a];
+      s->sort_inv_cell[a] = (ext > 0.0 && std::isfinite(ext)) ? (double)(1 << SORT_CELL_BITS) / ext : 0.0;
+    }
+    if (const char* e = getenv("RT_SORT_RAYS")) s->sort_enabled = s->sort_enabled && atoi(e) != 0;
+    if (const char* e = getenv("RT_SORT_MIN_LEVEL")) s->sort_min_level = std::max(1, atoi(e));
+  }
   s->info.device_bytes = 0;
   int rc;
   if ((rc = upload(s, groups, &s->d.groups))) return rc;
@@ -1013,7 +1247,7 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   if ((rc = upload(s, s->lights, &s->d.lights))) return rc;
   s->share_leaves = true;
   if (const char* e = getenv("RT_SHARE_LEAVES")) s->share_leaves = atoi(e) != 0;
-  if (const char* e = getenv("RT_FRAME_SPLIT")) s->frame_split = std::min(std::max(atoi(e), 1), 8);
+  if (const char* e = getenv("RT_FRAME_SPLIT")) s->frame_split = std::min(std::max(atoi(e), 0), 8);
   s->d.n_groups = (int32_t)groups.size();
   s->d.n_prims = (int32_t)prims.size();
   s->d.n_meshes = (int32_t)meshes.size();
@@ -1233,6 +1467,7 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
   long long level_n[MAX_DEPTH + 1];
   int levels = 0;
   bool spawned[MAX_DEPTH + 1] = {};
+  bool sorted_in = false;  // the queue the current level reads has been sorted
   int rc;
   for (int l = 0; l < depth; l++) {
     bool spawn = (l + 1 < depth);
@@ -1243,6 +1478,24 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
       if ((rc = wf_ensure(&w->wf_tasks[l + 1], &w->wf_task_cap[l + 1], (size_t)(2 * n), sizeof(WfTask))))
         return rc;
     }
+    // the queue this level fills is sorted before the next level reads it
+    const bool sort_next = spawn && s->sort_enabled && (l + 1) >= s->sort_min_level;
+    if (sort_next) {
+      if ((rc = wf_ensure(&w->wf_keys[l + 1], &w->wf_keys_cap[l + 1], w->wf_task_cap[l + 1], sizeof(unsigned int))))
+        return rc;
+      if (!w->wf_hist) {
+        HIP_TRY(hipMalloc(&w->wf_hist, 2 * (size_t)SORT_BINS * sizeof(unsigned int)));
+        HIP_TRY(hipMemsetAsync(w->wf_hist, 0, 2 * (size_t)SORT_BINS * sizeof(unsigned int), st));
+      }
+    }
+    SortGrid sgrid;
+    for (int a = 0; a < 3; a++) {
+      sgrid.lo[a] = s->sort_lo[a];
+      sgrid.inv_cell[a] = s->sort_inv_cell[a];
+    }
+    sgrid.enabled = sort_next ? 1 : 0;
+    const unsigned int* perm_in = sorted_in ? static_cast<const unsigned int*>(w->wf_perm[l]) : nullptr;
+    unsigned int* keys_next = sort_next ? static_cast<unsigned int*>(w->wf_keys[l + 1]) : nullptr;
     dim3 grid((unsigned)((n + WF_BLOCK - 1) / WF_BLOCK)), block(WF_BLOCK);
     const WfTask* tin = static_cast<const WfTask*>(w->wf_tasks[l]);
     WfNode* nodes = static_cast<WfNode*>(w->wf_nodes[l]);
@@ -1258,7 +1511,7 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
                      nodes, static_cast<uint8_t*>(w->wf_live[l]), parents, d_f64, d_u8, tnext, cnt_next, cap,   \
                      spawn ? 1 : 0, s->d_counters,                                                              \
                      (estimate && l > 0) ? w->wf_counts + 2 * l : (const unsigned int*)nullptr,                \
-                     w->wf_counts + OVERFLOW_SLOT)
+                     w->wf_counts + OVERFLOW_SLOT, sgrid, perm_in, keys_next, w->wf_hist)
 #define WF_LAUNCH2(ST, PR)              \
   do {                                  \
     if (fast && s->share_leaves)        \
@@ -1292,8 +1545,6 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
       const long long guess = (l + 1 < estimate->levels) ? estimate->n[l + 1] : 0;
       n = std::min(2 * n, guess + guess / 4 + 16384);
       n_front = n;  // the kernel reads both from the device
-      cap_in = cap;
-      continue;
     } else {
       HIP_TRY(hipMemcpyAsync(w->wf_counts_host + 2 * (l + 1), cnt_next, 2 * sizeof(unsigned int),
                              hipMemcpyDeviceToHost, st));
@@ -1304,7 +1555,24 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
       plan.front[l + 1] = n_front;
     }
     cap_in = cap;
-    if (n == 0) break;
+    sorted_in = false;
+    if (sort_next) {
+      // counting sort of the queue just filled: the histogram is complete, one block turns it
+      // into start positions (and zeroes it for its next use), one pass deals out the positions
+      hipLaunchKernelGGL(k_wf_sort_scan, dim3(1), dim3(1024), 0, st, w->wf_hist, w->wf_hist + SORT_BINS);
+      HIP_TRY(hipGetLastError());
+      s->launches++;
+      if (n > 0) {
+        if ((rc = wf_ensure(&w->wf_perm[l + 1], &w->wf_perm_cap[l + 1], (size_t)n, sizeof(unsigned int)))) return rc;
+        hipLaunchKernelGGL(k_wf_sort_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys_next, n, n_front,
+                           cap, w->wf_hist + SORT_BINS, static_cast<unsigned int*>(w->wf_perm[l + 1]),
+                           estimate ? w->wf_counts + 2 * (l + 1) : (const unsigned int*)nullptr);
+        HIP_TRY(hipGetLastError());
+        s->launches++;
+        sorted_in = true;
+      }
+    }
+    if (n == 0 && !estimate) break;
   }
   if (estimate) {
     // the true queue lengths follow the frame to the host; rt_estimated_frame_result reads them
@@ -1373,10 +1641,26 @@ static int render_device_fixed(rt_scene* s, const rt_camera* cam, int depth, int
   if (ntiles > 0 && pipeline == RT_PIPELINE_WAVEFRONT && depth > 0) {
     // interleaved sub-shards of this call's tiles, each a wavefront frame of its own
     int split = s->frame_split;
+    if (split == 0) {
+      // Not set by the host: a frame that has the GPU to itself is split in three, so that the
+      // thin end of one part's recursion level runs under another part's work; when frames of
+      // other streams are still in flight they fill those gaps already, and splitting would only
+      // add launches.  Sweeps that issue frames on estimates keep whole frames.
+      bool others_busy = s->allow_estimates;
+      for (const auto& c : s->caller_done) {
+        if (others_busy) break;
+        if (c.first != st && hipEventQuery(c.second) == hipErrorNotReady) others_busy = true;
+      }
+      (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure
+      split = others_busy ? 1 : 3;
+      if (getenv("RT_TRACE_SPLIT")) fprintf(stderr, "rt: split %d\n", split);
+    }
     if (ntiles < 64 * (int64_t)split) split = 1;  // too small to be worth the extra launches
     if (split > 1) s->allow_estimates = false;     // estimates are kept per caller stream
     if (split > 1) {
-      while ((int)s->split_streams.size() < split - 1) {
+      // every part runs on a stream of the scene's own (so the caller stream's ray queues stay
+      // sized for whole frames), forked from and joined to the caller's stream
+      while ((int)s->split_streams.size() < split) {
         hipStream_t q = nullptr;
         hipEvent_t e = nullptr;
         HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
@@ -1395,15 +1679,29 @@ static int render_device_fixed(rt_scene* s, const rt_camera* cam, int depth, int
       sub.out_k_add = i;
       const int64_t sub_tiles = rt_shard_tiles(cam->hsize, cam->vsize, sub.tile_first, sub.tile_step);
       if (sub_tiles <= 0) continue;
-      hipStream_t q = (i == 0) ? st : s->split_streams[i - 1];
-      if (i > 0) HIP_TRY(hipStreamWaitEvent(q, s->split_fork, 0));
+      hipStream_t q = (split == 1) ? st : s->split_streams[i];
+      if (split > 1) HIP_TRY(hipStreamWaitEvent(q, s->split_fork, 0));
       rc = render_wavefront(s, dc, sub, sub_tiles, depth, d_rgb_f64, d_rgb_u8, q, want_stats != 0,
                             mode == RT_MODE_F32_FAST);
       if (rc) return rc;
-      if (i > 0) {
-        HIP_TRY(hipEventRecord(s->split_joined[i - 1], q));
-        HIP_TRY(hipStreamWaitEvent(st, s->split_joined[i - 1], 0));
+      if (split > 1) {
+        HIP_TRY(hipEventRecord(s->split_joined[i], q));
+        HIP_TRY(hipStreamWaitEvent(st, s->split_joined[i], 0));
       }
+    }
+    {
+      // behind this frame on the caller's stream: tells later frames of other streams whether
+      // this one is still in flight
+      hipEvent_t* mine = nullptr;
+      for (auto& c : s->caller_done)
+        if (c.first == st) mine = &c.second;
+      if (!mine && s->caller_done.size() < 64) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s->caller_done.push_back({st, e});
+        mine = &s->caller_done.back().second;
+      }
+      if (mine) HIP_TRY(hipEventRecord(*mine, st));
     }
   } else if (ntiles > 0) {
     constexpr int PATCHES = (RT_TILE / 8) * (RT_TILE / 8);
@@ -1532,7 +1830,8 @@ int rt_render_device_noalloc(rt_scene* s, const rt_camera* cam, int depth, int m
 #define NA_LAUNCH(PR, FA)                                                                                   \
   hipLaunchKernelGGL((k_wf_level<false, PR, FA, true>), grid, block, 0, st, s->d, dc, pm, tin, n, n, cap_in, \
                      nodes, live, parents, d_rgb_f64, d_rgb_u8, tnext, counts + 2 * (l + 1), cap,            \
-                     spawn ? 1 : 0, s->d_counters, counts_in, counts + OVERFLOW_SLOT)
+                     spawn ? 1 : 0, s->d_counters, counts_in, counts + OVERFLOW_SLOT, SortGrid{}, (const unsigned int*)nullptr, \
+                     (unsigned int*)nullptr, (unsigned int*)nullptr)
       if (l == 0) {
         if (fast) NA_LAUNCH(true, true); else NA_LAUNCH(true, false);
       } else {

@@ -298,7 +298,7 @@ def turned(rt, base, angle, hsize=None, vsize=None):
     return c
 
 
-def test_sweep_of_new_cameras_is_issued_on_estimates(rt, O, pipeline):
+def test_sweep_of_new_cameras_is_issued_on_estimates(rt, O, pipeline, monkeypatch):
     """Cameras the scene has never rendered: after the first frame the sweep issues them without
     read-backs, sized from the latest finished frame.  Frames equal the ones rendered alone —
     also when an estimate does not hold (a frame of the empty sky followed by the glass pawn:
@@ -308,8 +308,9 @@ def test_sweep_of_new_cameras_is_issued_on_estimates(rt, O, pipeline):
     import torch
     if pipeline != "wavefront":
         pytest.skip("estimates belong to the wavefront pipeline")
-    if os.environ.get("RT_FRAME_SPLIT", "1") != "1":
-        pytest.skip("a frame split over internal streams is always issued the exact way")
+    # whole frames: a frame split over internal streams is always issued the exact way, and the
+    # queue lengths it leaves behind are those of its parts
+    monkeypatch.setenv("RT_FRAME_SPLIT", "1")
     w = rt.World.example("pawn", 640, 360)
     base = w.camera_abi()
     w.commit()
@@ -346,7 +347,7 @@ def test_sweep_of_new_cameras_is_issued_on_estimates(rt, O, pipeline):
     assert len(np.unique(got[-1])) > 50 and not np.array_equal(got[-1], got[0])
 
 
-def test_estimated_sweep_after_many_caller_streams(rt, pipeline):
+def test_estimated_sweep_after_many_caller_streams(rt, pipeline, monkeypatch):
     """More streams than the scene keeps ray-queue sets for: twelve caller streams render first,
     then a sweep of new cameras with seven frames in flight (eight slots of the scene's own) has
     to take sets over.  A set whose frame was issued on an estimate must not lose its verdict:
@@ -357,8 +358,9 @@ def test_estimated_sweep_after_many_caller_streams(rt, pipeline):
     import torch
     if pipeline != "wavefront":
         pytest.skip("estimates belong to the wavefront pipeline")
-    if os.environ.get("RT_FRAME_SPLIT", "1") != "1":
-        pytest.skip("a frame split over internal streams is always issued the exact way")
+    # whole frames: a frame split over internal streams is always issued the exact way, and the
+    # queue lengths it leaves behind are those of its parts
+    monkeypatch.setenv("RT_FRAME_SPLIT", "1")
     w = rt.World.example("pawn", 320, 180)
     base = w.camera_abi()
     w.commit()
