@@ -259,6 +259,9 @@ def main():
     # one frame at a time (not part of the timed region): mean over a few frames issued and
     # waited for one by one — what a host that wants ONE image gets
     single_n = 8
+    for _ in range(6):  # after four frames on one stream the library splits frames; the first split frame is planned
+        step(0)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(single_n):
         step(0)

@@ -128,12 +128,12 @@ struct rt_scene {
   // shard's level runs under another shard's work (RT_FRAME_SPLIT, 1 = off).
   int frame_split = 0;  // 0: decided per frame (see render_device_fixed)
   // coherence sort of the ray queues (see SortGrid): grid over the world-space bounds of the
-  // geometry; queues of level >= sort_min_level are sorted (RT_SORT_RAYS=0 switches it off)
+  // geometry; with RT_SORT_RAYS=1 the queues of level >= sort_min_level (RT_SORT_MIN_LEVEL) are sorted
   double sort_lo[3] = {0, 0, 0}, sort_inv_cell[3] = {0, 0, 0};
   bool sort_enabled = false;
-  int sort_min_level = 1;
+  int sort_min_level = 2;
   std::vector<hipStream_t> split_streams;
-  std::vector<std::pair<hipStream_t, hipEvent_t>> caller_done;  // per caller stream: behind its last frame
+  std::vector<hipStream_t> recent_streams;  // caller streams of the last four wavefront frames
   std::vector<hipEvent_t> split_joined;
   hipEvent_t split_fork = nullptr;
 };
@@ -910,7 +910,6 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->split_fork) (void)hipEventDestroy(s->split_fork);
     for (hipEvent_t e : s->split_joined) (void)hipEventDestroy(e);
     for (hipStream_t q : s->split_streams) (void)hipStreamDestroy(q);
-    for (auto& c : s->caller_done) (void)hipEventDestroy(c.second);
     for (rt_scene::SweepSlot& q : s->sweep_slots) {
       if (q.stream) (void)hipStreamDestroy(q.stream);
       if (q.device) (void)hipFree(q.device);
@@ -1230,7 +1229,11 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
       s->sort_lo[a] = glo[a];
       s->sort_inv_cell[a] = (ext > 0.0 && std::isfinite(ext)) ? (double)(1 << SORT_CELL_BITS) / ext : 0.0;
     }
-    if (const char* e = getenv("RT_SORT_RAYS")) s->sort_enabled = s->sort_enabled && atoi(e) != 0;
+    // Off unless asked for: measured on MI355X the sort raises the node loop's lane occupancy at
+    // the deep levels of the pawn frame from 24-32 to 32-37 of 64 and shortens those levels by
+    // 9-11 %, which its own passes (30 + 45-80 us per level) give back.
+    const char* want_sort = getenv("RT_SORT_RAYS");
+    s->sort_enabled = s->sort_enabled && want_sort && atoi(want_sort) != 0;
     if (const char* e = getenv("RT_SORT_MIN_LEVEL")) s->sort_min_level = std::max(1, atoi(e));
   }
   s->info.device_bytes = 0;
@@ -1642,19 +1645,20 @@ static int render_device_fixed(rt_scene* s, const rt_camera* cam, int depth, int
     // interleaved sub-shards of this call's tiles, each a wavefront frame of its own
     int split = s->frame_split;
     if (split == 0) {
-      // Not set by the host: a frame that has the GPU to itself is split in three, so that the
-      // thin end of one part's recursion level runs under another part's work; when frames of
-      // other streams are still in flight they fill those gaps already, and splitting would only
-      // add launches.  Sweeps that issue frames on estimates keep whole frames.
-      bool others_busy = s->allow_estimates;
-      for (const auto& c : s->caller_done) {
-        if (others_busy) break;
-        if (c.first != st && hipEventQuery(c.second) == hipErrorNotReady) others_busy = true;
-      }
-      (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure
-      split = others_busy ? 1 : 3;
+      // Not set by the host.  A split frame's parts overlap: the thin end of one part's recursion
+      // level runs under another part's work.  Sweeps that issue frames on estimates keep whole
+      // frames.
+      // A host that issues its frames on ONE stream renders one image at a time: each frame is
+      // split in three.  A host that spreads frames over several streams keeps frames in flight,
+      // which fills those gaps already; splitting would only add launches.  Decided from the
+      // streams of the last few frames, so the choice does not depend on timing.
+      bool one_stream = !s->allow_estimates && s->recent_streams.size() >= 4;
+      for (hipStream_t q : s->recent_streams) one_stream = one_stream && q == st;
+      split = one_stream ? 3 : 1;
       if (getenv("RT_TRACE_SPLIT")) fprintf(stderr, "rt: split %d\n", split);
     }
+    s->recent_streams.push_back(st);
+    if (s->recent_streams.size() > 4) s->recent_streams.erase(s->recent_streams.begin());
     if (ntiles < 64 * (int64_t)split) split = 1;  // too small to be worth the extra launches
     if (split > 1) s->allow_estimates = false;     // estimates are kept per caller stream
     if (split > 1) {
@@ -1688,20 +1692,6 @@ static int render_device_fixed(rt_scene* s, const rt_camera* cam, int depth, int
         HIP_TRY(hipEventRecord(s->split_joined[i], q));
         HIP_TRY(hipStreamWaitEvent(st, s->split_joined[i], 0));
       }
-    }
-    {
-      // behind this frame on the caller's stream: tells later frames of other streams whether
-      // this one is still in flight
-      hipEvent_t* mine = nullptr;
-      for (auto& c : s->caller_done)
-        if (c.first == st) mine = &c.second;
-      if (!mine && s->caller_done.size() < 64) {
-        hipEvent_t e = nullptr;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        s->caller_done.push_back({st, e});
-        mine = &s->caller_done.back().second;
-      }
-      if (mine) HIP_TRY(hipEventRecord(*mine, st));
     }
   } else if (ntiles > 0) {
     constexpr int PATCHES = (RT_TILE / 8) * (RT_TILE / 8);
