@@ -138,6 +138,9 @@ typedef struct rt_stats {
   /* iterations of the node loop and of the triangle loop counted once per 64-lane wave:
    * nodes_visited / (64 * node_wave_steps) is the fraction of lanes doing useful work there */
   uint64_t node_wave_steps, tri_wave_steps;
+  /* RT_MODE_F32_FAST only: candidates the f32 triangle search handed on, and how many triangle
+   * evaluations in f64 it took to settle what the f32 values could not */
+  uint64_t fast_candidates, fast_exact;
 } rt_stats;
 
 /* scene info after commit */

@@ -99,6 +99,8 @@ pub struct RtStats {
     pub max_nodes_per_query: u64,
     pub node_wave_steps: u64,
     pub tri_wave_steps: u64,
+    pub fast_candidates: u64,
+    pub fast_exact: u64,
 }
 
 extern "C" {

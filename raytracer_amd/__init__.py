@@ -73,7 +73,8 @@ class Stats(C.Structure):
         "pred_queries", "nodes_visited", "tri_tests", "prim_tests", "inst_entries", "shade_calls",
         "launches")] + [("kernel_ms", C.c_double), ("total_ms", C.c_double),
                         ("max_nodes_per_query", C.c_uint64), ("node_wave_steps", C.c_uint64),
-                        ("tri_wave_steps", C.c_uint64)]
+                        ("tri_wave_steps", C.c_uint64), ("fast_candidates", C.c_uint64),
+                        ("fast_exact", C.c_uint64)]
 
     def rays(self):
         return self.rays_primary + self.rays_shadow + self.rays_reflect + self.rays_refract
@@ -86,6 +87,8 @@ class Stats(C.Structure):
         d["max_nodes_per_query"] = int(self.max_nodes_per_query)
         d["node_wave_steps"] = int(self.node_wave_steps)
         d["tri_wave_steps"] = int(self.tri_wave_steps)
+        d["fast_candidates"] = int(self.fast_candidates)
+        d["fast_exact"] = int(self.fast_exact)
         return d
 
 

@@ -700,6 +700,7 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
            const unsigned int* counts_in, unsigned int* overflow, SortGrid grid, const unsigned int* perm,
            unsigned int* next_keys, unsigned int* hist) {
   static_assert(WF_BLOCK == 64, "the traversal stack is laid out for 64-lane blocks");
+  static_assert(COOP || !FAST, "the f32 search exists on the shared leaf tests only");
   RT_TRAV_STACK_COOP(st, S);
 #ifdef RT_SECTION_TIMES
   unsigned long long section_t_ = __builtin_readcyclecounter();
@@ -821,9 +822,9 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
   } else {
     if (active) {
       HitRec h;
-      if (trace_closest<STATS, FAST>(S, ray, h, cnt, st)) {
+      if (trace_closest<STATS>(S, ray, h, cnt, st)) {
         ShadeOut so;
-        shade_hit_local<STATS, FAST>(S, ray, h, so, cnt, st);
+        shade_hit_local<STATS>(S, ray, h, so, cnt, st);
         has_children = emit_result<STATS>(so, so.surface, nd, i, next, next_count, next_cap, spawn, cnt, grid, next_keys, hist);
       }
     }
@@ -1188,8 +1189,15 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
         TF.e2[a] = (float)T.e2[a];
       }
       TF.orig = T.orig;
-      TF.smooth = T.smooth;
-      TF.pad = 0;
+      uint32_t lo16[3];
+      for (int a = 0; a < 3; a++) {
+        const float r = (float)(T.p1[a] - (double)TF.p1[a]);  // what f32 lost
+        uint32_t bits;
+        std::memcpy(&bits, &r, sizeof bits);
+        lo16[a] = bits >> 16;  // truncated: at most 2^-7 of the residual is dropped
+      }
+      TF.p1_lo_xy = lo16[0] | (lo16[1] << 16);
+      TF.p1_lo_z = lo16[2];
       tris.push_back(T);
       trisf.push_back(TF);
       trin.push_back(TN);
@@ -1517,10 +1525,8 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
                      w->wf_counts + OVERFLOW_SLOT, sgrid, perm_in, keys_next, w->wf_hist)
 #define WF_LAUNCH2(ST, PR)              \
   do {                                  \
-    if (fast && s->share_leaves)        \
+    if (fast)                           \
       WF_LAUNCH(ST, PR, true, true);    \
-    else if (fast)                      \
-      WF_LAUNCH(ST, PR, true, false);   \
     else if (s->share_leaves)           \
       WF_LAUNCH(ST, PR, false, true);   \
     else                                \
@@ -1983,6 +1989,8 @@ int rt_render_stats(rt_scene* s, rt_stats* st) {
   st->shade_calls = c[10];
   st->node_wave_steps = c[11];
   st->tri_wave_steps = c[12];
+  st->fast_candidates = c[13];
+  st->fast_exact = c[14];
   st->launches = s->launches;
   return RT_OK;
 }

@@ -125,29 +125,65 @@ __device__ __forceinline__ bool moller_trumbore(const DTri& T, const Ray& r, dou
   return true;
 }
 
-// The same test in f32 (fast arithmetic mode): candidates are found with it, the winner is
-// evaluated again in f64.
+// The same test in f32 (fast arithmetic mode) with its own error bounds, so that it never
+// decides what it cannot know.  Inputs are the f64 operands rounded to f32 (relative error
+// d = 2^-24 each); the ray origin is re-based into the mesh's box, so every coordinate is of the
+// mesh's magnitude: |o_i| + |p1_i| <= Pm.  The offset p = o - p1 is formed from two-float values
+// (f32 + residual) of both, so it carries 2d |p_i| + 2^-31 Pm per component, not the 2d Pm of
+// plain f32 operands: a ray that starts 1e-5 off the surface it left (intersect.rs:184-185)
+// still sees on which side of that surface it is.  Below, Pm stands for that reduced term,
+// pm + Pm/64.  With the L1 norms dm = |dir|_1, e1m, e2m, pm = |p|_1, first-order bounds:
+//   dir x e2:   4d dm e2m per component         det = e1 . (dir x e2):  8d e1m dm e2m
+//   p . (dir x e2)   (u):  d dm e2m (4 Pm + 10 pm)
+//   p x e1:     d e1m (2 Pm + 4 pm) per component
+//   dir . (p x e1)   (v):  d dm e1m (2 Pm + 7 pm)
+//   e2 . (p x e1)    (t):  d e1m e2m (2 Pm + 8 pm)
+// and a quotient N/det is off by at most (err N + |N/det| err det) / |det|.  Every bound is
+// taken twice over.  The test answers
+//   FT_REJECT  the f64 test (ttriangle.rs:9-34) misses for certain,
+//   FT_SOLID   it hits for certain, at t within `et` of the f32 value,
+//   FT_UNSURE  anything else (an edge, the EPSILON cut on the determinant, a grazing ray):
+//              the caller evaluates the triangle in f64.
 struct RayF {
   float ox, oy, oz, dx, dy, dz;
+  float oxl, oyl, ozl;  // what f32 lost of the origin
 };
-__device__ __forceinline__ bool moller_trumbore_f32(const DTriF& T, const RayF& r, float& t, float& u,
-                                                    float& v) {
-  float cx = r.dy * T.e2[2] - r.dz * T.e2[1];
-  float cy = r.dz * T.e2[0] - r.dx * T.e2[2];
-  float cz = r.dx * T.e2[1] - r.dy * T.e2[0];
-  float det = T.e1[0] * cx + T.e1[1] * cy + T.e1[2] * cz;
-  if (fabsf(det) < (float)EPS) return false;
-  float f = 1.0f / det;
-  float px = r.ox - T.p1[0], py = r.oy - T.p1[1], pz = r.oz - T.p1[2];
-  u = f * (px * cx + py * cy + pz * cz);
-  if (!(u >= 0.0f && u <= 1.0f)) return false;
-  float qx = py * T.e1[2] - pz * T.e1[1];
-  float qy = pz * T.e1[0] - px * T.e1[2];
-  float qz = px * T.e1[1] - py * T.e1[0];
-  v = f * (r.dx * qx + r.dy * qy + r.dz * qz);
-  if (v < 0.0f || (u + v) > 1.0f) return false;
+enum { FT_REJECT = 0, FT_SOLID = 1, FT_UNSURE = 2 };
+__device__ __forceinline__ int moller_trumbore_f32(const DTriF& T, const RayF& r, float Pm, float dm, float& t,
+                                                   float& et) {
+  constexpr float D2 = 2.02f * 5.9604644775390625e-08f;  // twice 2^-24, and the quotient's own rounding
+  t = 0.0f;
+  et = __builtin_huge_valf();
+  const float cx = r.dy * T.e2[2] - r.dz * T.e2[1];
+  const float cy = r.dz * T.e2[0] - r.dx * T.e2[2];
+  const float cz = r.dx * T.e2[1] - r.dy * T.e2[0];
+  const float det = T.e1[0] * cx + T.e1[1] * cy + T.e1[2] * cz;
+  const float e1m = fabsf(T.e1[0]) + fabsf(T.e1[1]) + fabsf(T.e1[2]);
+  const float e2m = fabsf(T.e2[0]) + fabsf(T.e2[1]) + fabsf(T.e2[2]);
+  const float errdet = 8.0f * D2 * e1m * dm * e2m;
+  const float den = fabsf(det);
+  if (den < (float)EPS - errdet) return FT_REJECT;  // |det| < EPSILON in f64 too
+  if (!(den > 8.0f * errdet)) return FT_UNSURE;     // ill-conditioned (or NaN): nothing below can be trusted
+  const bool det_sure = den > (float)EPS + errdet;
+  const float f = 1.0f / det, fa = fabsf(f);
+  const float px = (r.ox - T.p1[0]) + (r.oxl - __uint_as_float(T.p1_lo_xy << 16));
+  const float py = (r.oy - T.p1[1]) + (r.oyl - __uint_as_float(T.p1_lo_xy & 0xffff0000u));
+  const float pz = (r.oz - T.p1[2]) + (r.ozl - __uint_as_float(T.p1_lo_z << 16));
+  const float pm = fabsf(px) + fabsf(py) + fabsf(pz);
+  Pm = pm + Pm * (1.0f / 64.0f);
+  const float u = f * (px * cx + py * cy + pz * cz);
+  const float eu = (D2 * dm * e2m * (4.0f * Pm + 10.0f * pm) + fmaxf(1.0f, fabsf(u)) * errdet) * fa;
+  if (u < -eu || u > 1.0f + eu) return FT_REJECT;
+  const float qx = py * T.e1[2] - pz * T.e1[1];
+  const float qy = pz * T.e1[0] - px * T.e1[2];
+  const float qz = px * T.e1[1] - py * T.e1[0];
+  const float v = f * (r.dx * qx + r.dy * qy + r.dz * qz);
+  const float ev = (D2 * dm * e1m * (2.0f * Pm + 7.0f * pm) + fmaxf(1.0f, fabsf(v)) * errdet) * fa;
+  if (v < -ev || (u + v) > 1.0f + (eu + ev)) return FT_REJECT;
   t = f * (T.e2[0] * qx + T.e2[1] * qy + T.e2[2] * qz);
-  return true;
+  et = (D2 * e1m * e2m * (2.0f * Pm + 8.0f * pm) + fabsf(t) * errdet) * fa;
+  const bool solid = det_sure && u > eu && u < 1.0f - eu && v > ev && (u + v) < 1.0f - (eu + ev) && (et < 1e30f);
+  return solid ? FT_SOLID : FT_UNSURE;
 }
 
 // f64::max / f64::min ignore a NaN operand (cube.rs:74-75, 85-92); so do fmax/fmin.
@@ -424,8 +460,8 @@ __device__ __forceinline__ DTriF decode_tri(const TriRawF& r) {
   t.e1[0] = __uint_as_float(r.a.w); t.e1[1] = __uint_as_float(r.b.x); t.e1[2] = __uint_as_float(r.b.y);
   t.e2[0] = __uint_as_float(r.b.z); t.e2[1] = __uint_as_float(r.b.w); t.e2[2] = __uint_as_float(r.c.x);
   t.orig = r.c.y;
-  t.smooth = r.c.z;
-  t.pad = 0;
+  t.p1_lo_xy = r.c.z;
+  t.p1_lo_z = r.c.w;
   return t;
 }
 __device__ __forceinline__ DTri decode_tri(const TriRaw& r) {
@@ -639,6 +675,10 @@ struct Query {
   bool found;
   int32_t mesh, tri;
   double u, v;
+  // fast mode only: how far the f32 value in `hi` (Q_CLOSEST) / `best.t` (Q_PRED) may be from the
+  // f64 one (0: it is the f64 value), and the record `best` belongs to
+  double tau;
+  int32_t best_rec;
 };
 
 // Accepts one candidate intersection (t, u, v of triangle `rec`) into the query.
@@ -701,9 +741,135 @@ __device__ __forceinline__ bool accept_hit_select(bool valid, double t, double u
     return false;
   }
 }
+// Fast mode: takes one candidate of the f32 search into the query.  `t` is the f32 value (on the
+// ray's own parameter), `et` its error bound, `cls` FT_SOLID or FT_UNSURE; `rec` the triangle's
+// record in the table, `lr` the ray in the mesh's space.  Whatever the f32 values cannot decide
+// for certain — an unsure triangle, t within its bound of 0 or of the interval's end, two
+// candidates closer together than their bounds — is decided by moller_trumbore() in f64 (rare:
+// a divergent branch), so the query ends with the triangle the f64 search would have found.
+// A best hit taken on an f32 value has q.tau > 0 until it is evaluated in f64 (at the latest
+// when the walk of its mesh ends).
+template <int MODE, bool STATS>
+__device__ inline bool accept_fast(const DScene& S, const Ray& lr, bool valid, int cls, double t, double et,
+                                   uint32_t ord, int m, int rec, Query& q, Counters& cnt) {
+  if (!valid) return false;
+  if (STATS) cnt.fast_candidates++;
+  bool exact = cls != FT_SOLID;
+  if (MODE == Q_CLOSEST) {
+    if (!exact) {
+      if (t < -et) return false;  // behind the origin for certain
+      const double band = q.tau + et;
+      if (!(t > et)) {
+        exact = true;  // the sign of t is open
+      } else if (t < q.hi - band) {
+        q.hi = t;
+        q.tau = et;
+        q.hi_order = ord;
+        q.mesh = m;
+        q.tri = rec;
+        q.found = true;
+        return false;
+      } else if (t > q.hi + band) {
+        return false;
+      } else {
+        exact = true;  // too close to the best so far to be ordered in f32
+      }
+    }
+    double te, ue, ve;
+    if (STATS) cnt.fast_exact++;
+    if (!moller_trumbore(S.tris[rec], lr, te, ue, ve) || !(te > 0.0)) return false;
+    if (q.found && q.tau > 0.0) {  // the best so far in f64 as well (it is a triangle of this mesh)
+      double tb, ub, vb;
+      if (moller_trumbore(S.tris[q.tri], lr, tb, ub, vb)) {
+        q.hi = tb;
+        q.u = ub;
+        q.v = vb;
+        q.tau = 0.0;
+      }
+    }
+    if (te < q.hi || (te == q.hi && ord < q.hi_order)) {
+      q.hi = te;
+      q.tau = 0.0;
+      q.hi_order = ord;
+      q.mesh = m;
+      q.tri = rec;
+      q.u = ue;
+      q.v = ve;
+      q.found = true;
+    }
+    return false;
+  } else if (MODE == Q_ANY) {
+    if (!exact) {
+      if (t > et && t < q.hi - et) return true;
+      if (t < -et || t > q.hi + et) return false;
+    }
+    double te, ue, ve;
+    if (STATS) cnt.fast_exact++;
+    return moller_trumbore(S.tris[rec], lr, te, ue, ve) && te > 0.0 && te < q.hi;
+  } else {
+    if (rec == q.tri) return false;  // the hit whose predecessor is sought
+    if (!exact) {
+      if (t > q.hi + et) return false;  // above the trigger for certain
+      const double band = q.tau + et;
+      if (!(t < q.hi - et)) {
+        exact = true;  // which side of the trigger?
+      } else if (!q.found || t > q.best.t + band) {
+        q.best = Key{t, ord, 0};
+        q.tau = et;
+        q.best_rec = rec;
+        q.mesh = m;
+        q.found = true;
+        return false;
+      } else if (t < q.best.t - band) {
+        return false;
+      } else {
+        exact = true;
+      }
+    }
+    double te, ue, ve;
+    if (STATS) cnt.fast_exact++;
+    if (!moller_trumbore(S.tris[rec], lr, te, ue, ve)) return false;
+    const Key c{te, ord, 0}, K{q.hi, q.hi_order, 0};
+    if (!key_less(c, K)) return false;
+    if (q.found && q.tau > 0.0) {
+      double tb, ub, vb;
+      if (moller_trumbore(S.tris[q.best_rec], lr, tb, ub, vb)) {
+        q.best.t = tb;
+        q.tau = 0.0;
+      }
+    }
+    if (!q.found || key_less(q.best, c)) {
+      q.best = c;
+      q.tau = 0.0;
+      q.best_rec = rec;
+      q.mesh = m;
+      q.found = true;
+    }
+    return false;
+  }
+}
+// Fast mode: the walk of mesh `m` is over; a best hit of it still held as an f32 value gets its
+// f64 value (what the parity mode computes for that triangle).
+template <int MODE>
+__device__ inline void settle_fast(const DScene& S, const Ray& lr, int m, Query& q) {
+  if (MODE == Q_ANY || !q.found || !(q.tau > 0.0) || q.mesh != m) return;
+  double tb, ub, vb;
+  const int rec = (MODE == Q_CLOSEST) ? q.tri : q.best_rec;
+  if (moller_trumbore(S.tris[rec], lr, tb, ub, vb)) {
+    if (MODE == Q_CLOSEST) {
+      q.hi = tb;
+      q.u = ub;
+      q.v = vb;
+    } else {
+      q.best.t = tb;
+    }
+  }
+  q.tau = 0.0;
+}
+
 template <int MODE, bool STATS>
 __device__ __forceinline__ bool test_tri(const DTri& T, uint32_t order_base, int m, int rec,
-                                         const Ray& lr, const RayF&, Query& q, Counters& cnt) {
+                                         const Ray& lr, Query& q, Counters& cnt) {
   double t, u, v;
   if (STATS) {
     if (wave_leader()) cnt.tri_wave_steps++;
@@ -712,33 +878,19 @@ __device__ __forceinline__ bool test_tri(const DTri& T, uint32_t order_base, int
   if (!moller_trumbore(T, lr, t, u, v)) return false;
   return accept_hit<MODE>(t, u, v, order_base + T.orig, m, rec, q);
 }
-template <int MODE, bool STATS>
-__device__ __forceinline__ bool test_tri(const DTriF& T, uint32_t order_base, int m, int rec,
-                                         const Ray&, const RayF& lrf, Query& q, Counters& cnt) {
-  float t, u, v;
-  if (STATS) {
-    if (wave_leader()) cnt.tri_wave_steps++;
-    cnt.tri_tests++;
-  }
-  if (!moller_trumbore_f32(T, lrf, t, u, v)) return false;
-  return accept_hit<MODE>((double)t, (double)u, (double)v, order_base + T.orig, m, rec, q);
-}
-
 // The triangles of one leaf, two at a time: both records are in flight together.  Which
 // triangle wins does not depend on the test order (the comparisons carry the leaf order).
-// TRI is DTri (f64 records) or DTriF (f32 records of the fast mode).
-template <int MODE, bool STATS, typename TRI>
-__device__ __forceinline__ bool test_leaf(uint32_t order_base, int tri_base, int m, const TRI* tris,
-                                          int first, int count, const Ray& lr, const RayF& lrf,
-                                          Query& q, Counters& cnt) {
+template <int MODE, bool STATS>
+__device__ __forceinline__ bool test_leaf(uint32_t order_base, int tri_base, int m, const DTri* tris,
+                                          int first, int count, const Ray& lr, Query& q, Counters& cnt) {
   for (int k = 0; k < count; k += 2) {
     const bool two = k + 1 < count;
     auto r0 = load_tri_raw(tris + first + k);
     auto r1 = load_tri_raw(tris + first + (two ? k + 1 : k));
     pin(r0, r1);
-    if (test_tri<MODE, STATS>(decode_tri(r0), order_base, m, tri_base + first + k, lr, lrf, q, cnt))
+    if (test_tri<MODE, STATS>(decode_tri(r0), order_base, m, tri_base + first + k, lr, q, cnt))
       return true;
-    if (two && test_tri<MODE, STATS>(decode_tri(r1), order_base, m, tri_base + first + k + 1, lr, lrf, q, cnt))
+    if (two && test_tri<MODE, STATS>(decode_tri(r1), order_base, m, tri_base + first + k + 1, lr, q, cnt))
       return true;
   }
   return false;
@@ -793,7 +945,7 @@ __device__ __forceinline__ int node_step(const NodeR& N, const CullRay& c, float
 }
 
 // Walks every mesh.  Returns true as soon as a Q_ANY query is satisfied.
-template <int MODE, bool STATS, bool FAST>
+template <int MODE, bool STATS>
 __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q, Counters& cnt,
                                        TravStack& st) {
   for (int m = 0; m < S.n_meshes; m++) {
@@ -805,8 +957,6 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
     const int tri_base = M.tri_base;
     const uint32_t order_base = M.order_base;
     const DTri* tris = S.tris + tri_base;
-    const DTriF* trisf = S.trisf + tri_base;
-    RayF lrf = {(float)lr.o.x, (float)lr.o.y, (float)lr.o.z, (float)lr.d.x, (float)lr.d.y, (float)lr.d.z};
     // query interval in t - t_base, rounded outward
     float qlo, qhi;
     if (MODE == Q_PRED) {
@@ -842,8 +992,7 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
       }
       if (cur <= -2) {
         int code = -2 - cur;
-        const bool done = FAST ? test_leaf<MODE, STATS>(order_base, tri_base, m, trisf, code >> LEAF_BITS, code & LEAF_MAX, lr, lrf, q, cnt)
-                               : test_leaf<MODE, STATS>(order_base, tri_base, m, tris, code >> LEAF_BITS, code & LEAF_MAX, lr, lrf, q, cnt);
+        const bool done = test_leaf<MODE, STATS>(order_base, tri_base, m, tris, code >> LEAF_BITS, code & LEAF_MAX, lr, q, cnt);
         if (done) return true;
         // a leaf may have tightened the interval
         if (MODE == Q_CLOSEST) {
@@ -891,12 +1040,16 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
     const uint32_t order_base = M.order_base;
     const DTri* tris = S.tris + tri_base;
     const DTriF* trisf = S.trisf + tri_base;
-    // every lane publishes its object-space ray for the workers
+    // every lane publishes its object-space ray for the workers (fast mode: with the origin moved
+    // to where the ray enters the mesh's box, so that the f32 test works on coordinates of the
+    // mesh's own magnitude; its t then counts from c.t_base)
     {
+      V3 po = lr.o;
+      if (FAST) po = ray_at(lr, c.t_base);
       u32x4 w0, w1, w2;
-      w0.x = (unsigned)__double2loint(lr.o.x); w0.y = (unsigned)__double2hiint(lr.o.x);
-      w0.z = (unsigned)__double2loint(lr.o.y); w0.w = (unsigned)__double2hiint(lr.o.y);
-      w1.x = (unsigned)__double2loint(lr.o.z); w1.y = (unsigned)__double2hiint(lr.o.z);
+      w0.x = (unsigned)__double2loint(po.x); w0.y = (unsigned)__double2hiint(po.x);
+      w0.z = (unsigned)__double2loint(po.y); w0.w = (unsigned)__double2hiint(po.y);
+      w1.x = (unsigned)__double2loint(po.z); w1.y = (unsigned)__double2hiint(po.z);
       w1.z = (unsigned)__double2loint(lr.d.x); w1.w = (unsigned)__double2hiint(lr.d.x);
       w2.x = (unsigned)__double2loint(lr.d.y); w2.y = (unsigned)__double2hiint(lr.d.y);
       w2.z = (unsigned)__double2loint(lr.d.z); w2.w = (unsigned)__double2hiint(lr.d.z);
@@ -913,6 +1066,7 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
       qlo = f32_down(0.0 - c.t_base);
       qhi = (q.hi < 1e300) ? f32_up(q.hi - c.t_base) : __builtin_huge_valf();
     }
+    const float mesh_scale = (float)M.scale * 1.0001f;
     int sp = 0;
     int cur = (walking0 && !c.miss) ? M.root : -1;
     unsigned long long visited = 0;
@@ -960,7 +1114,8 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
         const int o_first = __shfl(lfirst, o, 64);
         bool ok = false;
         double wt = 0.0, wu = 0.0, wv = 0.0;  // the worker's result
-        uint32_t worig = 0;
+        float wft = 0.f, wfe = 0.f;           // ... in fast mode: f32 t (from c.t_base) and its error bound
+        uint32_t worig = 0;                   // (fast mode: the test's verdict in the two top bits)
         if (work) {
           const int rec = o_first + (s - o_off);
           if (STATS) {
@@ -970,17 +1125,23 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
           const u32x4 w0 = st.rays[3 * o + 0], w1 = st.rays[3 * o + 1], w2 = st.rays[3 * o + 2];
           if (FAST) {
             RayF rf;
-            rf.ox = (float)__hiloint2double((int)w0.y, (int)w0.x);
-            rf.oy = (float)__hiloint2double((int)w0.w, (int)w0.z);
-            rf.oz = (float)__hiloint2double((int)w1.y, (int)w1.x);
+            const double ox = __hiloint2double((int)w0.y, (int)w0.x), oy = __hiloint2double((int)w0.w, (int)w0.z),
+                         oz = __hiloint2double((int)w1.y, (int)w1.x);
+            rf.ox = (float)ox;
+            rf.oy = (float)oy;
+            rf.oz = (float)oz;
+            rf.oxl = (float)(ox - (double)rf.ox);
+            rf.oyl = (float)(oy - (double)rf.oy);
+            rf.ozl = (float)(oz - (double)rf.oz);
             rf.dx = (float)__hiloint2double((int)w1.w, (int)w1.z);
             rf.dy = (float)__hiloint2double((int)w2.y, (int)w2.x);
             rf.dz = (float)__hiloint2double((int)w2.w, (int)w2.z);
             const DTriF T = decode_tri(load_tri_raw(trisf + rec));
-            float t, u, v;
-            ok = moller_trumbore_f32(T, rf, t, u, v) && (MODE == Q_PRED || t > 0.0f);
-            wt = (double)t; wu = (double)u; wv = (double)v;
-            worig = T.orig;
+            const float Pm = (fmaxf(fmaxf(fabsf(rf.ox), fabsf(rf.oy)), fabsf(rf.oz)) + mesh_scale) * 1.0001f;
+            const float dm = (fabsf(rf.dx) + fabsf(rf.dy) + fabsf(rf.dz)) * 1.0001f;
+            const int cls = moller_trumbore_f32(T, rf, Pm, dm, wft, wfe);
+            ok = cls != FT_REJECT;
+            worig = T.orig | ((uint32_t)cls << 30);
           } else {
             Ray r;
             r.o = v3(__hiloint2double((int)w0.y, (int)w0.x), __hiloint2double((int)w0.w, (int)w0.z),
@@ -1003,10 +1164,16 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
         while (__ballot(mine != 0ull) != 0ull) {  // wave-uniform
           const int k = mine ? __ffsll((long long)mine) - 1 : 0;
           const int src = mine ? lo + k : lane;  // worker lane holding my next candidate
-          const double t = __shfl(wt, src, 64), u = __shfl(wu, src, 64), v = __shfl(wv, src, 64);
           const uint32_t orig = (uint32_t)__shfl((int)worig, src, 64);
           const int rec = lfirst + (base + lo + k - off);
-          hit_any |= accept_hit_select<MODE>(mine != 0ull, t, u, v, order_base + orig, m, tri_base + rec, q);
+          if (FAST) {
+            const double t = (double)__shfl(wft, src, 64) + c.t_base, et = (double)__shfl(wfe, src, 64);
+            hit_any |= accept_fast<MODE, STATS>(S, lr, mine != 0ull, (int)(orig >> 30), t, et,
+                                                order_base + (orig & 0x3fffffffu), m, tri_base + rec, q, cnt);
+          } else {
+            const double t = __shfl(wt, src, 64), u = __shfl(wu, src, 64), v = __shfl(wv, src, 64);
+            hit_any |= accept_hit_select<MODE>(mine != 0ull, t, u, v, order_base + orig, m, tri_base + rec, q);
+          }
           mine &= mine - 1ull;  // 0 stays 0
         }
       }
@@ -1016,28 +1183,32 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
           satisfied = true;
           cur = -1;
         } else {
+          // (q.tau: fast mode's bound on an f32 value; 0 otherwise)
           if (MODE == Q_CLOSEST) {
-            if (q.hi < 1e300) qhi = f32_up(q.hi - c.t_base);
+            if (q.hi < 1e300) qhi = f32_up((q.hi + q.tau) - c.t_base);
           } else if (MODE == Q_PRED) {
-            if (q.found) qlo = f32_down(q.best.t - c.t_base);
+            if (q.found) qlo = f32_down((q.best.t - q.tau) - c.t_base);
           }
           cur = sp ? st.get(--sp) : -1;
         }
       }
     }
+    if (FAST && walking0) settle_fast<MODE>(S, lr, m, q);
   }
   return satisfied;
 }
 
 // hit() of intersect.rs:125-139 over the list of world.rs:22-32: smallest t > 0, the
 // earliest leaf among equal t.
-template <bool STATS, bool FAST = false>
+template <bool STATS>
 __device__ inline bool trace_closest(const DScene& S, const Ray& ray, HitRec& h, Counters& cnt,
                                      TravStack& st) {
   Query q;
   q.hi = RT_INF;
   q.hi_order = 0xffffffffu;
   q.found = false;
+  q.tau = 0.0;
+  q.best_rec = -1;
   q.mesh = -1;
   q.tri = -1;
   q.u = 0.0;
@@ -1061,20 +1232,7 @@ __device__ inline bool trace_closest(const DScene& S, const Ray& ray, HitRec& h,
       }
     }
   }
-  int prim_before = q.mesh;  // stays -1 unless a triangle wins
-  traverse_meshes<Q_CLOSEST, STATS, FAST>(S, ray, q, cnt, st);
-  if (FAST && q.mesh >= 0) {
-    // the f32 search picked the triangle; t, u, v of the pick in f64 when the f64 test agrees
-    const DMesh& M = S.meshes[q.mesh];
-    Ray lr = ray_to_group(S, M.group, ray);
-    double t, u, v;
-    if (moller_trumbore(S.tris[q.tri], lr, t, u, v) && t > 0.0) {
-      q.hi = t;
-      q.u = u;
-      q.v = v;
-    }
-  }
-  (void)prim_before;
+  traverse_meshes<Q_CLOSEST, STATS>(S, ray, q, cnt, st);
   h.t = q.hi;
   h.order = q.hi_order;
   h.u = q.u;
@@ -1087,7 +1245,7 @@ __device__ inline bool trace_closest(const DScene& S, const Ray& ray, HitRec& h,
 
 // is_shadowed (world.rs:116-134): the nearest positive hit is closer than `distance`
 // exactly when some intersection has 0 < t < distance.
-template <bool STATS, bool FAST = false>
+template <bool STATS>
 __device__ inline bool trace_any(const DScene& S, const Ray& ray, double distance, Counters& cnt,
                                  TravStack& st) {
   const BoxRay br = make_box_ray(ray);
@@ -1105,9 +1263,11 @@ __device__ inline bool trace_any(const DScene& S, const Ray& ray, double distanc
   q.hi = distance;
   q.hi_order = 0;
   q.found = false;
+  q.tau = 0.0;
+  q.best_rec = -1;
   q.mesh = -1;
   q.tri = -1;
-  return traverse_meshes<Q_ANY, STATS, FAST>(S, ray, q, cnt, st);
+  return traverse_meshes<Q_ANY, STATS>(S, ray, q, cnt, st);
 }
 
 // The key a predecessor query actually has to search below.  The hit is the smallest
@@ -1125,16 +1285,18 @@ __device__ __forceinline__ Key predecessor_bound(const Key& K) {
 // Largest key below K among all triangle intersections of the infinite line (t may be
 // negative).  Every triangle is its own shape with at most one entry, so this is the last
 // triangle still "open" when the containers walk of intersect.rs:188-222 reaches K.
-template <bool STATS, bool FAST = false>
+template <bool STATS>
 __device__ inline bool tri_predecessor(const DScene& S, const Ray& ray, const Key& K, int own_tri,
                                        Key& best, int& best_mesh, Counters& cnt, TravStack& st) {
   Query q;
   q.hi = K.t;
   q.hi_order = K.order;
   q.found = false;
+  q.tau = 0.0;
+  q.best_rec = -1;
   q.mesh = -1;
   q.tri = own_tri;
-  traverse_meshes<Q_PRED, STATS, FAST>(S, ray, q, cnt, st);
+  traverse_meshes<Q_PRED, STATS>(S, ray, q, cnt, st);
   if (q.found) {
     best = q.best;
     best_mesh = q.mesh;
@@ -1151,6 +1313,8 @@ __device__ inline bool trace_closest_coop(const DScene& S, const Ray& ray, bool 
   q.hi = RT_INF;
   q.hi_order = 0xffffffffu;
   q.found = false;
+  q.tau = 0.0;
+  q.best_rec = -1;
   q.mesh = -1;
   q.tri = -1;
   q.u = 0.0;
@@ -1178,16 +1342,6 @@ __device__ inline bool trace_closest_coop(const DScene& S, const Ray& ray, bool 
     }
   }
   traverse_meshes_coop<Q_CLOSEST, STATS, FAST>(S, ray, q, enabled, cnt, st);
-  if (FAST && enabled && q.mesh >= 0) {
-    const DMesh& M = S.meshes[q.mesh];
-    Ray lr = ray_to_group(S, M.group, ray);
-    double t, u, v;
-    if (moller_trumbore(S.tris[q.tri], lr, t, u, v) && t > 0.0) {
-      q.hi = t;
-      q.u = u;
-      q.v = v;
-    }
-  }
   h.t = q.hi;
   h.order = q.hi_order;
   h.u = q.u;
@@ -1219,6 +1373,8 @@ __device__ inline bool trace_any_coop(const DScene& S, const Ray& ray, double di
   q.hi = distance;
   q.hi_order = 0;
   q.found = false;
+  q.tau = 0.0;
+  q.best_rec = -1;
   q.mesh = -1;
   q.tri = -1;
   q.u = q.v = 0.0;
@@ -1235,6 +1391,8 @@ __device__ inline bool tri_predecessor_coop(const DScene& S, const Ray& ray, con
   q.hi = K.t;
   q.hi_order = K.order;
   q.found = false;
+  q.tau = 0.0;
+  q.best_rec = -1;
   q.mesh = -1;
   q.tri = own_tri;
   q.u = q.v = 0.0;
@@ -1342,7 +1500,7 @@ __device__ inline void containers_from(const DScene& S, const Ray& ray, const Hi
     n2 = own_ri;  // the hit enters its own shape, which becomes the last container
 }
 
-template <bool STATS, bool FAST = false>
+template <bool STATS>
 __device__ inline void containers_n1_n2(const DScene& S, const Ray& ray, const HitRec& h,
                                         double own_ri, double& n1, double& n2, Counters& cnt,
                                         TravStack& st) {
@@ -1351,7 +1509,7 @@ __device__ inline void containers_n1_n2(const DScene& S, const Ray& ray, const H
   Key tb{0.0, 0u, 0};
   int tm = -1;
   bool tf = (S.n_meshes > 0) &&
-            tri_predecessor<STATS, FAST>(S, ray, predecessor_bound(K), h.prim >= 0 ? -1 : h.tri, tb, tm, cnt, st);
+            tri_predecessor<STATS>(S, ray, predecessor_bound(K), h.prim >= 0 ? -1 : h.tri, tb, tm, cnt, st);
   containers_from<STATS>(S, ray, h, K, own_ri, tf, tb, tm, n1, n2, cnt);
 }
 
@@ -1543,7 +1701,7 @@ __device__ inline void finish_optics(const DMaterial& M, const Ray& ray, const P
 }
 
 // prepare_computations + the light loop of shade_hit + the child-ray set-up, in one lane.
-template <bool STATS, bool FAST = false>
+template <bool STATS>
 __device__ inline void shade_hit_local(const DScene& S, const Ray& ray, const HitRec& h,
                                        ShadeOut& o, Counters& cnt, TravStack& st) {
   if (STATS) cnt.shade_calls++;
@@ -1566,13 +1724,13 @@ __device__ inline void shade_hit_local(const DScene& S, const Ray& ray, const Hi
     double distance;
     shadow_ray(L, pr.over, sr, distance);
     if (STATS) cnt.rays_shadow++;
-    bool shadow = trace_any<STATS, FAST>(S, sr, distance, cnt, st);
+    bool shadow = trace_any<STATS>(S, sr, distance, cnt, st);
     // lightv = normalize(light.position - position) is the shadow ray's direction
     add_light(M, L, pc, sr.d, pr.normal, eyev, shadow, surface);
   }
   o.surface = surface;
   double n1 = 1.0, n2 = 1.0;
-  if (needs_n1_n2(M)) containers_n1_n2<STATS, FAST>(S, ray, h, M.refractive_index, n1, n2, cnt, st);
+  if (needs_n1_n2(M)) containers_n1_n2<STATS>(S, ray, h, M.refractive_index, n1, n2, cnt, st);
   finish_optics(M, ray, pr, n1, n2, o);
 }
 

@@ -40,10 +40,12 @@ struct alignas(16) DTri {
   uint32_t orig;    // index in face order (for the leaf order and tie-breaks)
   uint32_t smooth;  // 1: interpolate vertex normals, 0: flat normal
 };
-// The same triangle in f32 for the fast arithmetic mode.  48 bytes.
+// The same triangle in f32 for the fast arithmetic mode.  48 bytes.  p1 is kept to about 2^-31
+// of its magnitude: p1_lo holds the upper 16 bits of the three f32 residuals p1 - f32(p1)
+// (x | y << 16, z), so that (origin - p1) can be formed without the f32 rounding of either.
 struct alignas(16) DTriF {
   float p1[3], e1[3], e2[3];
-  uint32_t orig, smooth, pad;
+  uint32_t orig, p1_lo_xy, p1_lo_z;
 };
 // Normals, fetched only for the final hit: n1,n2,n3 (smooth) or the flat normal in n[0..2].
 struct alignas(8) DTriN {
@@ -109,9 +111,10 @@ struct DCamera {
 struct Counters {
   unsigned long long rays_primary, rays_shadow, rays_reflect, rays_refract, depth0_skipped,
       pred_queries, nodes_visited, tri_tests, prim_tests, inst_entries, shade_calls,
-      node_wave_steps, tri_wave_steps;  // iterations of the node / triangle loop, per wave
+      node_wave_steps, tri_wave_steps,  // iterations of the node / triangle loop, per wave
+      fast_candidates, fast_exact;      // fast mode: f32 candidates handed to their owners / f64 evaluations
   unsigned long long max_nodes;  // not a sum: the longest single traversal (nodes)
 };
-constexpr int N_COUNTERS = 13;  // summed counters; max_nodes is stored after them
+constexpr int N_COUNTERS = 15;  // summed counters; max_nodes is stored after them
 
 }  // namespace rtd

@@ -36,7 +36,7 @@ def test_struct_sizes_match_header(rt):
     # rt_material: 7 doubles + 2 int32 + 3+3+16 doubles; rt_camera: 2 int32 + 3 + 16 doubles
     assert C.sizeof(rt.Material) == 8 * 7 + 8 + 8 * 22
     assert C.sizeof(rt.CameraABI) == 8 + 8 * 19
-    assert C.sizeof(rt.Stats) == 8 * 12 + 16 + 8 * 3
+    assert C.sizeof(rt.Stats) == 8 * 12 + 16 + 8 * 5
 
 
 def test_host_matrix_math_is_bitwise_the_oracles(rt, O):
