@@ -205,6 +205,25 @@ int64_t rt_shard_tiles(int hsize, int vsize, int tile_first, int tile_step);
 int rt_detile_u8(const uint8_t* d_tiles, int nshards, int64_t tiles_per_shard, int hsize,
                  int vsize, uint8_t* d_image, void* hip_stream);
 
+/* ---- several GPUs of one node ------------------------------------------------------------ */
+/* Replaces what scene::camera::render does with threads: the shared World/Camera
+ * (Arc, camera.rs:95-100), the bands of rows (camera.rs:114-143), join and stitch_canvases
+ * (camera.rs:147-162, canvas.rs:47-64).  rt_scene_commit_multi commits the scene to every
+ * listed GPU (device_ids distinct; the first one assembles the frames) and sets up RCCL between
+ * them (librccl is loaded on this call, not before).  rt_render_multi deals the frame's
+ * RT_TILE x RT_TILE tiles round-robin to the GPUs, every GPU renders its tiles, ONE exchange
+ * (grouped ncclSend/ncclRecv of the compact u8 tile buffers to the first GPU) and a de-tile
+ * kernel there produce the row-major image: out_rgb_u8 (host) and/or d_rgb_u8 (device memory on
+ * device_ids[0]); at least one must be given.  The image is the one rt_render produces, byte for
+ * byte, for every ndev; ndev = 1 runs the same steps (its shard goes through RCCL to itself).
+ * stats (may be NULL): counters summed over the GPUs, kernel_ms the slowest GPU's.
+ * One host thread per scene; the call returns when the image is complete. */
+int rt_scene_commit_multi(rt_scene*, const int* device_ids, int ndev, int bvh_builder);
+int rt_render_multi(rt_scene*, const rt_camera*, int depth, int mode, int pipeline,
+                    uint8_t* out_rgb_u8, uint8_t* d_rgb_u8, rt_stats* stats);
+/* GPUs a committed scene lives on (1 after rt_scene_commit), 0 if not committed */
+int rt_scene_device_count(const rt_scene*);
+
 /* ---- a render entry point that allocates nothing --------------------------------------- */
 /* No counterpart in the reference.  For callers that cannot allocate device memory while they
  * render: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.

@@ -170,6 +170,9 @@ def lib():
     L.rth_set_camera.argtypes = [vp, C.c_int, C.c_int, C.c_double, dp]
     L.rth_get_camera.argtypes = [vp, C.POINTER(CameraABI)]
     L.rth_commit.argtypes = [vp, C.c_int, C.c_int]
+    L.rth_commit_multi.argtypes = [vp, C.POINTER(C.c_int), C.c_int, C.c_int]
+    L.rt_render_multi.argtypes = [vp, C.POINTER(CameraABI), C.c_int, C.c_int, C.c_int, u8p, vp, C.POINTER(Stats)]
+    L.rt_scene_device_count.argtypes = [vp]
     L.rth_scene.argtypes = [vp]
     L.rth_scene.restype = vp
     L.rth_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, u8p, C.POINTER(Stats)]
@@ -288,6 +291,29 @@ class World:
             self._err("commit")
         self.committed = True
         return self
+
+    def commit_multi(self, devices, bvh_builder=0):
+        """rt_scene_commit_multi: the scene on several GPUs; render() then uses all of them."""
+        devs = (C.c_int * len(devices))(*devices)
+        if self.L.rth_commit_multi(self.h, devs, len(devices), bvh_builder) != 0:
+            self._err("commit_multi")
+        self.committed = True
+        return self
+
+    def render_multi(self, d_u8=None, want_host=True, depth=5, mode=MODE_F64_PARITY, pipeline=None,
+                     want_stats=False, cam=None):
+        """rt_render_multi: returns (u8 HxWx3 or None, Stats or None); d_u8 = device pointer on the
+        first GPU for the stitched image."""
+        pipeline = DEFAULT_PIPELINE if pipeline is None else pipeline
+        cam = cam or self.camera_abi()
+        u8 = np.zeros(cam.hsize * cam.vsize * 3, dtype=np.uint8) if want_host else None
+        st = Stats() if want_stats else None
+        rc = self.L.rt_render_multi(self.scene, C.byref(cam), depth, mode, pipeline,
+                                    u8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_host else None,
+                                    C.c_void_p(d_u8 or 0), C.byref(st) if want_stats else None)
+        if rc != 0:
+            raise RtError(f"rt_render_multi: {self.L.rt_last_error().decode()}")
+        return (u8.reshape(cam.vsize, cam.hsize, 3) if want_host else None), st
 
     @property
     def scene(self):

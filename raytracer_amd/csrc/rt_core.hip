@@ -2,6 +2,9 @@
 // upload), the render kernels and their launchers.  gfx950 only; there is no CPU path —
 // every entry point that needs the GPU fails with RT_ERR_NO_DEVICE / RT_ERR_HIP without one.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
 
 #include <chrono>
 #include <cmath>
@@ -41,6 +44,7 @@ struct MeshH {
   bool has_normals;
 };
 
+struct Multi;
 struct rt_scene {
   std::vector<rt_material> mats;
   std::vector<rt_group> groups;
@@ -134,6 +138,10 @@ struct rt_scene {
   int sort_min_level = 2;
   std::vector<hipStream_t> split_streams;
   std::vector<hipStream_t> recent_streams;  // caller streams of the last four wavefront frames
+  // A shard of one tile still goes to a compact tile buffer, not to the row-major image (set on
+  // the replicas of a multi-GPU scene, whose one shard of one is stitched like any other).
+  bool compact_always = false;
+  struct Multi* multi = nullptr;  // rt_scene_commit_multi: replicas on other GPUs, RCCL, buffers
   std::vector<hipEvent_t> split_joined;
   hipEvent_t split_fork = nullptr;
 };
@@ -897,8 +905,14 @@ int rt_device_count(void) {
 
 rt_scene* rt_scene_create(void) { return new rt_scene(); }
 
+static void multi_destroy(struct Multi* m);
 void rt_scene_destroy(rt_scene* s) {
   if (!s) return;
+  if (s->multi) {
+    Multi* m = s->multi;
+    s->multi = nullptr;
+    multi_destroy(m);  // the replicas on the other GPUs, the communicators, the exchange buffers
+  }
   if (s->device >= 0) {  // also after a commit that failed half way: what it uploaded is freed
     int cur = 0;
     (void)hipGetDevice(&cur);
@@ -1316,14 +1330,14 @@ static int camera_to_device(const rt_camera* c, DCamera& d) {
 }
 
 // A whole call's pixel map: all the image row-major, or a shard into its compact tile buffer.
-static PixelMap pixel_map(const rt_camera* cam, int tile_first, int tile_step) {
+static PixelMap pixel_map(const rt_camera* cam, int tile_first, int tile_step, bool compact_always = false) {
   PixelMap pm;
   pm.hsize = cam->hsize;
   pm.vsize = cam->vsize;
   pm.tiles_x = (cam->hsize + RT_TILE - 1) / RT_TILE;
   pm.tile_first = tile_first;
   pm.tile_step = tile_step;
-  pm.out_row_major = (tile_step == 1) ? 1 : 0;
+  pm.out_row_major = (tile_step == 1 && !compact_always) ? 1 : 0;
   pm.out_k_mul = 1;
   pm.out_k_add = 0;
   return pm;
@@ -1643,7 +1657,7 @@ static int render_device_fixed(rt_scene* s, const rt_camera* cam, int depth, int
   if (ntiles < 0) return fail(RT_ERR_ARG, "bad tile shard");
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   HIP_TRY(hipSetDevice(s->device));
-  const PixelMap pm = pixel_map(cam, tile_first, tile_step);
+  const PixelMap pm = pixel_map(cam, tile_first, tile_step, s->compact_always);
   if (want_stats) HIP_TRY(hipMemsetAsync(s->d_counters, 0, (N_COUNTERS + 1) * sizeof(unsigned long long), st));
   HIP_TRY(hipEventRecord(s->ev0, st));
   s->launches = 0;
@@ -1933,7 +1947,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, int depth, int mode, int
   DCamera dc;
   int rc = camera_to_device(cam, dc);
   if (rc) return rc;
-  const PixelMap pm = pixel_map(cam, tile_first, tile_step);
+  const PixelMap pm = pixel_map(cam, tile_first, tile_step, s->compact_always);
   const uint64_t key = frame_key(dc, pm, depth, false);
   for (const auto& kv : s->auto_choice)
     if (kv.first == key)
@@ -2068,6 +2082,247 @@ int rt_trace_rays(rt_scene* s, int64_t n, const double* origins, const double* d
   (void)hipFree(d_d);
   (void)hipFree(d_out);
   if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("rt_trace_rays: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
+// =======================================================================================
+// Several GPUs of one node, one host thread.  The reference shares World and Camera between
+// threads (Arc, camera.rs:95-100), gives each a band of rows (camera.rs:114-143), joins them and
+// stitches the bands (camera.rs:147-162, canvas.rs:47-64).  Here the scene is replicated on
+// every GPU, the frame's 32x32-pixel tiles are dealt round-robin to the GPUs (bands would be
+// badly balanced: glass pixels cost several times what floor pixels do), and ONE exchange ends
+// the frame: every GPU sends its compact tile buffer to the first one (grouped ncclSend/ncclRecv:
+// each peer has its own xGMI link into it), which stitches them (k_detile_u8).
+// RCCL is loaded when the first multi-GPU scene is committed (dlopen), so a process that
+// renders on one GPU through the other entry points never touches it.
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static Rccl g_rccl;
+static int rccl_load() {
+  if (g_rccl.lib) return RT_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names)
+    if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!h) return fail(RT_ERR_UNSUPPORTED, std::string("RCCL not found (librccl.so.1): ") + dlerror());
+  Rccl r;
+  r.lib = h;
+#define RT_SYM(field, name)                                                                \
+  r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name));                            \
+  if (!r.field) return fail(RT_ERR_UNSUPPORTED, std::string("RCCL lacks ") + name)
+  RT_SYM(CommInitAll, "ncclCommInitAll");
+  RT_SYM(CommDestroy, "ncclCommDestroy");
+  RT_SYM(GroupStart, "ncclGroupStart");
+  RT_SYM(GroupEnd, "ncclGroupEnd");
+  RT_SYM(Send, "ncclSend");
+  RT_SYM(Recv, "ncclRecv");
+  RT_SYM(GetErrorString, "ncclGetErrorString");
+#undef RT_SYM
+  g_rccl = r;
+  return RT_OK;
+}
+#define NCCL_TRY(expr)                                                                              \
+  do {                                                                                              \
+    ncclResult_t r_ = (expr);                                                                       \
+    if (r_ != ncclSuccess) return fail(RT_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+  } while (0)
+
+struct Multi {
+  std::vector<int> devs;
+  std::vector<rt_scene*> scenes;  // scenes[0] is the scene the caller holds; the others are its replicas
+  std::vector<ncclComm_t> comms;
+  std::vector<hipStream_t> streams;
+  std::vector<uint8_t*> d_tiles;  // per GPU: its shard's compact tile buffer
+  size_t tiles_cap = 0;           // bytes of each
+  uint8_t* d_all = nullptr;       // first GPU: every shard's buffer back to back
+  size_t all_cap = 0;
+  uint8_t* d_image = nullptr;     // first GPU: the stitched image, when the caller gave no device buffer
+  size_t image_cap = 0;
+};
+
+static void multi_destroy(Multi* m) {
+  if (!m) return;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (size_t d = 0; d < m->devs.size(); d++) {
+    (void)hipSetDevice(m->devs[d]);
+    if (d < m->comms.size() && m->comms[d] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comms[d]);
+    if (d < m->streams.size() && m->streams[d]) (void)hipStreamDestroy(m->streams[d]);
+    if (d < m->d_tiles.size() && m->d_tiles[d]) (void)hipFree(m->d_tiles[d]);
+    if (d == 0) {
+      if (m->d_all) (void)hipFree(m->d_all);
+      if (m->d_image) (void)hipFree(m->d_image);
+    }
+    if (d > 0 && d < m->scenes.size() && m->scenes[d]) rt_scene_destroy(m->scenes[d]);
+  }
+  (void)hipSetDevice(cur);
+  delete m;
+}
+
+int rt_scene_commit_multi(rt_scene* s, const int* device_ids, int ndev, int bvh_builder) {
+  if (!s || !device_ids) return fail(RT_ERR_ARG, "null argument");
+  if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
+  const int visible = rt_device_count();
+  if (visible <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible; the render core has no CPU path");
+  if (ndev < 1 || ndev > 64) return fail(RT_ERR_ARG, "ndev must be 1..64");
+  for (int a = 0; a < ndev; a++) {
+    if (device_ids[a] < 0 || device_ids[a] >= visible) return fail(RT_ERR_ARG, "device index out of range");
+    for (int b = 0; b < a; b++)
+      if (device_ids[a] == device_ids[b]) return fail(RT_ERR_ARG, "device listed twice");
+  }
+  int rc = rccl_load();
+  if (rc) return rc;
+  int previous = 0;
+  HIP_TRY(hipGetDevice(&previous));
+  Multi* m = new Multi;
+  m->devs.assign(device_ids, device_ids + ndev);
+  m->scenes.assign((size_t)ndev, nullptr);
+  m->scenes[0] = s;
+  s->multi = m;  // from here on rt_scene_destroy(s) releases everything below
+  for (int d = 1; d < ndev; d++) {  // replicas: the same description, committed to the other GPUs
+    rt_scene* r = new rt_scene();
+    r->mats = s->mats;
+    r->groups = s->groups;
+    r->prims = s->prims;
+    r->prim_order = s->prim_order;
+    r->meshes = s->meshes;
+    r->lights = s->lights;
+    r->next_order = s->next_order;
+    m->scenes[(size_t)d] = r;
+  }
+  for (int d = 0; d < ndev; d++) {
+    rt_scene* r = m->scenes[(size_t)d];
+    if ((rc = rt_scene_commit(r, m->devs[(size_t)d], bvh_builder))) return rc;
+    r->compact_always = true;
+    if (d > 0) {  // a replica's host copy of the geometry has served its purpose
+      std::vector<MeshH>().swap(r->meshes);
+    }
+  }
+  m->comms.assign((size_t)ndev, nullptr);
+  NCCL_TRY(g_rccl.CommInitAll(m->comms.data(), ndev, m->devs.data()));
+  m->streams.assign((size_t)ndev, nullptr);
+  m->d_tiles.assign((size_t)ndev, nullptr);
+  for (int d = 0; d < ndev; d++) {
+    HIP_TRY(hipSetDevice(m->devs[(size_t)d]));
+    HIP_TRY(hipStreamCreateWithFlags(&m->streams[(size_t)d], hipStreamNonBlocking));
+  }
+  HIP_TRY(hipSetDevice(previous));
+  return RT_OK;
+}
+
+int rt_scene_device_count(const rt_scene* s) {
+  if (!s || !s->committed) return 0;
+  return s->multi ? (int)s->multi->devs.size() : 1;
+}
+
+int rt_render_multi(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline, uint8_t* out_rgb_u8,
+                    uint8_t* d_rgb_u8, rt_stats* stats) {
+  if (!s || !cam) return fail(RT_ERR_ARG, "null argument");
+  if (!s->committed || !s->multi) return fail(RT_ERR_STATE, "scene not committed with rt_scene_commit_multi");
+  if (cam->hsize <= 0 || cam->vsize <= 0) return fail(RT_ERR_ARG, "camera size must be positive");
+  if (!out_rgb_u8 && !d_rgb_u8) return fail(RT_ERR_ARG, "no output buffer");
+  Multi* m = s->multi;
+  const int ndev = (int)m->devs.size();
+  auto t0 = std::chrono::steady_clock::now();
+  int previous = 0;
+  HIP_TRY(hipGetDevice(&previous));
+  int64_t per = 0;
+  for (int d = 0; d < ndev; d++) per = std::max(per, rt_shard_tiles(cam->hsize, cam->vsize, d, ndev));
+  const size_t bytes_per = (size_t)per * RT_TILE * RT_TILE * 3;
+  const size_t npx = (size_t)cam->hsize * cam->vsize;
+  if (bytes_per > m->tiles_cap) {
+    for (int d = 0; d < ndev; d++) {
+      HIP_TRY(hipSetDevice(m->devs[(size_t)d]));
+      HIP_TRY(hipStreamSynchronize(m->streams[(size_t)d]));
+      if (m->d_tiles[(size_t)d]) (void)hipFree(m->d_tiles[(size_t)d]);
+      m->d_tiles[(size_t)d] = nullptr;
+      HIP_TRY(hipMalloc((void**)&m->d_tiles[(size_t)d], bytes_per));
+    }
+    m->tiles_cap = bytes_per;
+  }
+  HIP_TRY(hipSetDevice(m->devs[0]));
+  if (bytes_per * (size_t)ndev > m->all_cap) {
+    HIP_TRY(hipStreamSynchronize(m->streams[0]));
+    if (m->d_all) (void)hipFree(m->d_all);
+    m->d_all = nullptr;
+    m->all_cap = 0;
+    HIP_TRY(hipMalloc((void**)&m->d_all, bytes_per * (size_t)ndev));
+    m->all_cap = bytes_per * (size_t)ndev;
+  }
+  uint8_t* image = d_rgb_u8;
+  if (!image) {
+    if (npx * 3 > m->image_cap) {
+      HIP_TRY(hipStreamSynchronize(m->streams[0]));
+      if (m->d_image) (void)hipFree(m->d_image);
+      m->d_image = nullptr;
+      m->image_cap = 0;
+      HIP_TRY(hipMalloc((void**)&m->d_image, npx * 3));
+      m->image_cap = npx * 3;
+    }
+    image = m->d_image;
+  }
+  // every GPU renders its tiles (scene replicated, no communication) ...
+  int rc;
+  for (int d = 0; d < ndev; d++) {
+    HIP_TRY(hipSetDevice(m->devs[(size_t)d]));
+    if ((rc = rt_render_device(m->scenes[(size_t)d], cam, depth, mode, pipeline, d, ndev, nullptr, m->d_tiles[(size_t)d],
+                               m->streams[(size_t)d], stats ? 1 : 0)))
+      return rc;
+  }
+  // ... and ONE exchange: all shards to the first GPU.  The first GPU's own shard travels the
+  // same way (a send to itself), so one GPU alone runs the code path of eight.
+  NCCL_TRY(g_rccl.GroupStart());
+  for (int d = 0; d < ndev; d++) {
+    ncclResult_t r1 = g_rccl.Send(m->d_tiles[(size_t)d], bytes_per, ncclUint8, 0, m->comms[(size_t)d], m->streams[(size_t)d]);
+    ncclResult_t r2 = g_rccl.Recv(m->d_all + (size_t)d * bytes_per, bytes_per, ncclUint8, d, m->comms[0], m->streams[0]);
+    if (r1 != ncclSuccess || r2 != ncclSuccess) {
+      (void)g_rccl.GroupEnd();
+      return fail(RT_ERR_HIP, std::string("ncclSend/ncclRecv: ") + g_rccl.GetErrorString(r1 != ncclSuccess ? r1 : r2));
+    }
+  }
+  NCCL_TRY(g_rccl.GroupEnd());
+  HIP_TRY(hipSetDevice(m->devs[0]));
+  if ((rc = rt_detile_u8(m->d_all, ndev, per, cam->hsize, cam->vsize, image, m->streams[0]))) return rc;
+  if (out_rgb_u8) HIP_TRY(hipMemcpyAsync(out_rgb_u8, image, npx * 3, hipMemcpyDeviceToHost, m->streams[0]));
+  for (int d = ndev - 1; d >= 0; d--) {
+    HIP_TRY(hipSetDevice(m->devs[(size_t)d]));
+    HIP_TRY(hipStreamSynchronize(m->streams[(size_t)d]));
+  }
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    for (int d = 0; d < ndev; d++) {
+      rt_stats one;
+      if ((rc = rt_render_stats(m->scenes[(size_t)d], &one))) return rc;
+      stats->rays_primary += one.rays_primary;
+      stats->rays_shadow += one.rays_shadow;
+      stats->rays_reflect += one.rays_reflect;
+      stats->rays_refract += one.rays_refract;
+      stats->depth0_skipped += one.depth0_skipped;
+      stats->pred_queries += one.pred_queries;
+      stats->nodes_visited += one.nodes_visited;
+      stats->tri_tests += one.tri_tests;
+      stats->prim_tests += one.prim_tests;
+      stats->inst_entries += one.inst_entries;
+      stats->shade_calls += one.shade_calls;
+      stats->launches += one.launches;
+      stats->node_wave_steps += one.node_wave_steps;
+      stats->tri_wave_steps += one.tri_wave_steps;
+      stats->fast_candidates += one.fast_candidates;
+      stats->fast_exact += one.fast_exact;
+      stats->kernel_ms = std::max(stats->kernel_ms, one.kernel_ms);  // the GPUs render side by side
+      stats->max_nodes_per_query = std::max(stats->max_nodes_per_query, one.max_nodes_per_query);
+    }
+    stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  HIP_TRY(hipSetDevice(previous));
   return RT_OK;
 }
 

@@ -1,7 +1,8 @@
 // rt_cli.cpp — command line of the reference (src/main.rs:13-55) on top of the GPU core.
 //   -t/--threads N   accepted for compatibility (main.rs:19-26); the GPU needs no thread count
 //   -e/--example X   "cover" (default) | "pawn" | "tea set"   (main.rs:27-35, 46-51)
-// Additions: --width/--height (override the example's size), --gpu N, --obj-dir DIR,
+// Additions: --width/--height (override the example's size), --gpu N (which GPU), --gpus N (how many:
+// devices 0..N-1 share the frame's tiles, one RCCL gather), --mode f64|f32, --obj-dir DIR,
 // --out FILE (default canvas.ppm, main.rs:54; a name ending in .png is written as PNG), --stats,
 // --sweep N (a turntable of N frames over one committed scene: FILE_000, FILE_001, ...).
 #include <cstdio>
@@ -15,7 +16,7 @@
 
 int main(int argc, char** argv) {
   std::string example = "cover", out = "canvas.ppm", obj_dir = "./obj";
-  int width = 0, height = 0, gpu = -1, sweep = 0;
+  int width = 0, height = 0, gpu = -1, gpus = 0, sweep = 0, mode = RT_MODE_F64_PARITY;
   bool stats = false;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
@@ -36,6 +37,22 @@ int main(int argc, char** argv) {
       height = std::atoi(next());
     } else if (a == "--gpu") {
       gpu = std::atoi(next());
+    } else if (a == "--gpus") {
+      gpus = std::atoi(next());
+      if (gpus < 1) {
+        std::fprintf(stderr, "--gpus needs a positive number\n");
+        return 2;
+      }
+    } else if (a == "--mode") {
+      const std::string m = next();
+      if (m == "f64") {
+        mode = RT_MODE_F64_PARITY;
+      } else if (m == "f32") {
+        mode = RT_MODE_F32_FAST;
+      } else {
+        std::fprintf(stderr, "error: '%s' isn't a valid value for '--mode' (f64, f32)\n", m.c_str());
+        return 2;
+      }
     } else if (a == "--obj-dir") {
       obj_dir = next();
     } else if (a == "--out") {
@@ -57,6 +74,8 @@ int main(int argc, char** argv) {
     auto scene = rt::examples::by_name(example, obj_dir, width, height);
     rt::RenderOptions opt;
     opt.device = gpu;
+    opt.gpus = gpus;
+    opt.mode = mode;
     rt_stats st;
     if (stats) opt.stats = &st;
     const bool png = out.size() >= 4 && out.compare(out.size() - 4, 4, ".png") == 0;
@@ -86,7 +105,10 @@ int main(int argc, char** argv) {
       }
       return 0;
     }
-    std::printf("Rendering image on GPU %d\n", gpu < 0 ? 0 : gpu);
+    if (gpus > 0)
+      std::printf("Rendering image on %d GPU(s)\n", gpus);  // camera.rs:111
+    else
+      std::printf("Rendering image on GPU %d\n", gpu < 0 ? 0 : gpu);
     rt::Canvas image = rt::render(scene.first, scene.second, opt);
     if (!(png ? image.write_to_png(out) : image.write_to_ppm(out))) {
       std::fprintf(stderr, "could not create file %s\n", out.c_str());

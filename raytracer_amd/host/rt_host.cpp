@@ -654,11 +654,12 @@ struct Flattener {
 DeviceScene::~DeviceScene() {
   if (scene_) rt_scene_destroy(scene_);
 }
-bool DeviceScene::commit(const World& world, int device, int bvh_builder) {
+bool DeviceScene::flatten(const World& world) {
   if (scene_) {
     rt_scene_destroy(scene_);
     scene_ = nullptr;
   }
+  multi_ = false;
   scene_ = rt_scene_create();
   Flattener f{scene_, {}};
   for (const auto& o : world.objects)
@@ -674,10 +675,23 @@ bool DeviceScene::commit(const World& world, int device, int bvh_builder) {
       return false;
     }
   }
+  return true;
+}
+bool DeviceScene::commit(const World& world, int device, int bvh_builder) {
+  if (!flatten(world)) return false;
   if (rt_scene_commit(scene_, device, bvh_builder) != RT_OK) {
     error_ = rt_last_error();
     return false;
   }
+  return true;
+}
+bool DeviceScene::commit(const World& world, const std::vector<int>& devices, int bvh_builder) {
+  if (!flatten(world)) return false;
+  if (rt_scene_commit_multi(scene_, devices.data(), (int)devices.size(), bvh_builder) != RT_OK) {
+    error_ = rt_last_error();
+    return false;
+  }
+  multi_ = true;
   return true;
 }
 
@@ -689,14 +703,28 @@ Canvas render(const Camera& camera, DeviceScene& scene, const RenderOptions& opt
   c.rgb8.resize(n);
   if (opt.keep_f64) c.rgb.resize(n);
   rt_camera cam = camera.to_abi();
-  int rc = rt_render(scene.handle(), &cam, opt.depth, opt.mode, opt.pipeline,
-                     opt.keep_f64 ? c.rgb.data() : nullptr, c.rgb8.data(), opt.stats);
+  int rc;
+  if (scene.multi()) {
+    if (opt.keep_f64) throw std::runtime_error("render: a frame over several GPUs is delivered quantised only");
+    rc = rt_render_multi(scene.handle(), &cam, opt.depth, opt.mode, opt.pipeline, c.rgb8.data(), nullptr, opt.stats);
+  } else {
+    rc = rt_render(scene.handle(), &cam, opt.depth, opt.mode, opt.pipeline,
+                   opt.keep_f64 ? c.rgb.data() : nullptr, c.rgb8.data(), opt.stats);
+  }
   if (rc != RT_OK) throw std::runtime_error(std::string("render: ") + rt_last_error());
   return c;
 }
 Canvas render(const Camera& camera, const World& world, const RenderOptions& opt) {
   DeviceScene ds;
-  if (!ds.commit(world, opt.device)) throw std::runtime_error("render: " + ds.error());
+  bool ok;
+  if (opt.gpus > 0) {
+    std::vector<int> devices;
+    for (int d = 0; d < opt.gpus; d++) devices.push_back(d);
+    ok = ds.commit(world, devices);
+  } else {
+    ok = ds.commit(world, opt.device);
+  }
+  if (!ok) throw std::runtime_error("render: " + ds.error());
   return render(camera, ds, opt);
 }
 

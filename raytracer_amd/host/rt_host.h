@@ -196,16 +196,25 @@ class DeviceScene {
   // Flattens `world` depth-first (the order the reference's sorts see) and commits it.
   // Returns false and sets error() on failure.
   bool commit(const World& world, int device = -1, int bvh_builder = 0);
+  // The same scene on several GPUs of the node (the first one assembles the frames): what the
+  // reference does with `thread_count` threads (camera.rs:83-163).  render() then deals the
+  // frame's tiles to all of them.
+  bool commit(const World& world, const std::vector<int>& devices, int bvh_builder = 0);
+  bool multi() const { return multi_; }
   rt_scene* handle() const { return scene_; }
   const std::string& error() const { return error_; }
 
  private:
+  bool flatten(const World& world);
   rt_scene* scene_ = nullptr;
+  bool multi_ = false;
   std::string error_;
 };
 
 struct RenderOptions {
-  int device = -1;  // takes the place of `thread_count` (camera.rs:83): which GPU renders
+  int device = -1;  // which GPU renders ...
+  int gpus = 0;     // ... or, when > 0, how many (devices 0 .. gpus-1, through rt_scene_commit_multi /
+                    // rt_render_multi even for one): takes the place of `thread_count` (camera.rs:83)
   int depth = 5;    // camera.rs:178
   int mode = RT_MODE_F64_PARITY;
   int pipeline = RT_PIPELINE_WAVEFRONT;

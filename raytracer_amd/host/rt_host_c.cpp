@@ -215,6 +215,22 @@ int rth_commit(rth_world* w, int device, int bvh_builder) {
   });
 }
 
+int rth_commit_multi(rth_world* w, const int* device_ids, int ndev, int bvh_builder) {
+  if (!w || !device_ids || ndev < 1) return -1;
+  if (w->committed) {
+    g_herr = "world already committed";
+    return -1;
+  }
+  return guarded([&] {
+    if (!w->device.commit(w->world, std::vector<int>(device_ids, device_ids + ndev), bvh_builder)) {
+      g_herr = w->device.error();
+      return -1;
+    }
+    w->committed = true;
+    return 0;
+  });
+}
+
 rt_scene* rth_scene(rth_world* w) { return (w && w->committed) ? w->device.handle() : nullptr; }
 
 int rth_render(rth_world* w, int depth, int mode, int pipeline, double* out_rgb_f64,
@@ -225,7 +241,16 @@ int rth_render(rth_world* w, int depth, int mode, int pipeline, double* out_rgb_
   }
   return guarded([&] {
     rt_camera cam = w->camera.to_abi();
-    int rc = rt_render(w->device.handle(), &cam, depth, mode, pipeline, out_rgb_f64, out_rgb_u8, stats);
+    int rc;
+    if (w->device.multi()) {
+      if (out_rgb_f64) {
+        g_herr = "a frame over several GPUs is delivered quantised only";
+        return -1;
+      }
+      rc = rt_render_multi(w->device.handle(), &cam, depth, mode, pipeline, out_rgb_u8, nullptr, stats);
+    } else {
+      rc = rt_render(w->device.handle(), &cam, depth, mode, pipeline, out_rgb_f64, out_rgb_u8, stats);
+    }
     if (rc != RT_OK) {
       g_herr = rt_last_error();
       return -rc;

@@ -700,11 +700,54 @@ def test_pawn_8k_tile_shards(rt, O, pipeline):
         torch.cuda.synchronize()
         assert torch.equal(img, full), nshards
         del tiles, img
+    # the library-owned path (rt_scene_commit_multi / rt_render_multi: tiles, RCCL exchange, de-tile)
+    wm = rt.World.example("pawn", hs, vs).commit_multi([0])
+    img = torch.zeros((vs, hs, 3), dtype=torch.uint8, device="cuda")
+    wm.render_multi(d_u8=img.data_ptr(), want_host=False)
+    assert torch.equal(img, full)
+    del img, wm
     sc = O.Scene.example("pawn", hs, vs).use_bvh()
     rng = np.random.default_rng(12)
     xs, ys = rng.integers(0, hs, 30000).astype(np.int32), rng.integers(0, vs, 30000).astype(np.int32)
     _, ou8, _ = sc.render_pixels(xs, ys)
     assert np.array_equal(full.cpu().numpy()[ys, xs], ou8)
+
+
+def test_render_multi_on_one_gpu_equals_render(rt, O, pipeline, tmp_path):
+    """rt_scene_commit_multi / rt_render_multi with one GPU run every step of the multi-GPU
+    frame — compact tile buffer, the RCCL exchange (the shard is sent to itself), the de-tile
+    kernel — and must deliver the image rt_render delivers, byte for byte; so must the command
+    line with --gpus 1."""
+    import os
+    import subprocess
+    import torch
+    pipe = rt.PIPELINE_WAVEFRONT if pipeline == "wavefront" else rt.PIPELINE_MEGAKERNEL
+    hs, vs = 250, 141  # ragged: partial tiles on both edges
+    ref, _, rst = rt.World.example("pawn", hs, vs).commit().render(pipeline=pipe, want_stats=True)
+    w = rt.World.example("pawn", hs, vs).commit_multi([0])
+    assert w.L.rt_scene_device_count(w.scene) == 1
+    for _ in range(3):  # unseen, planned, planned
+        got, st = w.render_multi(pipeline=pipe, want_stats=True)
+        assert np.array_equal(got, ref)
+        assert st.rays() == rst.rays() and st.rays_shadow == rst.rays_shadow
+    dev = torch.zeros((vs, hs, 3), dtype=torch.uint8, device="cuda")
+    got, _ = w.render_multi(d_u8=dev.data_ptr(), want_host=False, pipeline=pipe)
+    assert got is None and np.array_equal(dev.cpu().numpy(), ref)
+    u8, _, _ = w.render(pipeline=pipe)  # the host mirror's render() on a multi scene
+    assert np.array_equal(u8, ref)
+    with pytest.raises(rt.RtError):
+        rt.World.example("cover", 32, 32).commit_multi([0, 0])
+    with pytest.raises(rt.RtError):
+        rt.World.example("cover", 32, 32).commit_multi([99])
+    if pipeline == "wavefront":
+        repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        out = tmp_path / "multi.png"
+        r = subprocess.run([os.path.join(repo, "raytracer_amd", "rt_cli"), "-e", "pawn", "--width", str(hs), "--height",
+                            str(vs), "--gpus", "1", "--obj-dir", os.path.join(repo, "assets", "obj"), "--out", str(out)],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert "on 1 GPU(s)" in r.stdout
+        assert np.array_equal(O.read_png_rgb8(str(out)), ref)
 
 
 @pytest.mark.parametrize("split", [2, 3])
