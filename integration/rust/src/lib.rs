@@ -103,6 +103,26 @@ pub struct RtStats {
     pub fast_exact: u64,
 }
 
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct RtSceneInfo {
+    pub n_groups: i64,
+    pub n_primitives: i64,
+    pub n_meshes: i64,
+    pub n_triangles: i64,
+    pub n_materials: i64,
+    pub n_lights: i64,
+    pub n_bvh_nodes: i64,
+    pub device_bytes: i64,
+    pub node_bytes: i32,
+    pub tri_bytes: i32,
+    pub device: i32,
+    pub bvh_builder: i32,
+    pub commit_ms: f64,
+}
+pub const RT_TILE: i32 = 32;
+pub const RT_NOALLOC_MAX_TILES: i64 = 8192;
+
 extern "C" {
     pub fn rt_last_error() -> *const c_char;
     pub fn rt_device_count() -> c_int;
@@ -124,6 +144,60 @@ extern "C" {
         out_rgb_u8: *mut u8,
         stats: *mut RtStats,
     ) -> c_int;
+    pub fn rt_scene_get_info(s: *const c_void, info: *mut RtSceneInfo) -> c_int;
+    /// Device buffers, asynchronous on `hip_stream` (a `hipStream_t`); renders the tiles
+    /// `t % tile_step == tile_first` (include/rt_core.h).
+    pub fn rt_render_device(
+        s: *mut c_void,
+        cam: *const RtCamera,
+        depth: c_int,
+        mode: c_int,
+        pipeline: c_int,
+        tile_first: c_int,
+        tile_step: c_int,
+        d_rgb_f64: *mut f64,
+        d_rgb_u8: *mut u8,
+        hip_stream: *mut c_void,
+        want_stats: c_int,
+    ) -> c_int;
+    pub fn rt_render_stats(s: *mut c_void, stats: *mut RtStats) -> c_int;
+    pub fn rt_shard_tiles(hsize: c_int, vsize: c_int, tile_first: c_int, tile_step: c_int) -> i64;
+    pub fn rt_detile_u8(
+        d_tiles: *const u8,
+        nshards: c_int,
+        tiles_per_shard: i64,
+        hsize: c_int,
+        vsize: c_int,
+        d_image: *mut u8,
+        hip_stream: *mut c_void,
+    ) -> c_int;
+    pub fn rt_scene_commit_multi(s: *mut c_void, device_ids: *const c_int, ndev: c_int, bvh_builder: c_int) -> c_int;
+    pub fn rt_render_multi(
+        s: *mut c_void,
+        cam: *const RtCamera,
+        depth: c_int,
+        mode: c_int,
+        pipeline: c_int,
+        out_rgb_u8: *mut u8,
+        d_rgb_u8: *mut u8,
+        stats: *mut RtStats,
+    ) -> c_int;
+    pub fn rt_scene_device_count(s: *const c_void) -> c_int;
+    pub fn rt_render_device_noalloc(
+        s: *mut c_void,
+        cam: *const RtCamera,
+        depth: c_int,
+        mode: c_int,
+        tile_first: c_int,
+        tile_step: c_int,
+        d_rgb_f64: *mut f64,
+        d_rgb_u8: *mut u8,
+        hip_stream: *mut c_void,
+    ) -> c_int;
+    pub fn rt_noalloc_max_tiles(depth: c_int) -> i64;
+    /// `out`: 32 doubles per ray (layout in include/rt_core.h).
+    pub fn rt_trace_rays(s: *mut c_void, n: i64, origins: *const f64, directions: *const f64, depth: c_int,
+                         out: *mut f64) -> c_int;
 }
 
 /// Error text of the last failed call on this thread.
@@ -187,6 +261,17 @@ impl SceneBuilder {
         let rc = unsafe { rt_scene_add_light(self.raw, intensity.as_ptr(), position.as_ptr()) };
         self.index(rc, "rt_scene_add_light")
     }
+    /// The scene on several GPUs of the node (`thread_count` of camera.rs:83 becomes a list of
+    /// devices); `Scene::render_rgb8` then deals the frame's tiles to all of them.
+    pub fn commit_multi(self, devices: &[i32], bvh_builder: i32) -> Scene {
+        let rc = unsafe { rt_scene_commit_multi(self.raw, devices.as_ptr(), devices.len() as c_int, bvh_builder) };
+        if rc != 0 {
+            panic!("rt_scene_commit_multi: {}", last_error());
+        }
+        let raw = self.raw;
+        std::mem::forget(self);
+        Scene { raw, multi: true }
+    }
     /// Builds the BVHs and uploads the scene; `bvh_builder` 0 = host SAH, 1 = device LBVH.
     pub fn commit(self, device: i32, bvh_builder: i32) -> Scene {
         let rc = unsafe { rt_scene_commit(self.raw, device, bvh_builder) };
@@ -195,7 +280,7 @@ impl SceneBuilder {
         }
         let raw = self.raw;
         std::mem::forget(self);
-        Scene { raw }
+        Scene { raw, multi: false }
     }
 }
 impl Drop for SceneBuilder {
@@ -207,17 +292,61 @@ impl Drop for SceneBuilder {
 /// A committed, immutable scene resident on one GPU.
 pub struct Scene {
     raw: *mut c_void,
+    multi: bool,
 }
 impl Scene {
+    pub fn info(&self) -> RtSceneInfo {
+        let mut i = RtSceneInfo::default();
+        if unsafe { rt_scene_get_info(self.raw, &mut i) } != 0 {
+            panic!("rt_scene_get_info: {}", last_error());
+        }
+        i
+    }
+    /// Counters of one frame (the kernels run with counters enabled).
+    pub fn render_rgb8_with_stats(&self, cam: &RtCamera, depth: i32) -> (Vec<u8>, RtStats) {
+        let mut rgb = vec![0u8; cam.hsize as usize * cam.vsize as usize * 3];
+        let mut st = RtStats::default();
+        let rc = unsafe {
+            if self.multi {
+                rt_render_multi(self.raw, cam, depth, RT_MODE_F64_PARITY, RT_PIPELINE_WAVEFRONT, rgb.as_mut_ptr(),
+                                std::ptr::null_mut(), &mut st)
+            } else {
+                rt_render(self.raw, cam, depth, RT_MODE_F64_PARITY, RT_PIPELINE_WAVEFRONT, std::ptr::null_mut(),
+                          rgb.as_mut_ptr(), &mut st)
+            }
+        };
+        if rc != 0 {
+            panic!("render: {}", last_error());
+        }
+        (rgb, st)
+    }
+    /// The known-answer interface: 32 doubles per ray (include/rt_core.h).
+    pub fn trace_rays(&self, origins: &[[f64; 3]], directions: &[[f64; 3]], depth: i32) -> Vec<[f64; 32]> {
+        assert!(origins.len() == directions.len());
+        let mut out = vec![[0f64; 32]; origins.len()];
+        let rc = unsafe {
+            rt_trace_rays(self.raw, origins.len() as i64, origins.as_ptr() as *const f64,
+                          directions.as_ptr() as *const f64, depth, out.as_mut_ptr() as *mut f64)
+        };
+        if rc != 0 {
+            panic!("rt_trace_rays: {}", last_error());
+        }
+        out
+    }
     /// One frame, quantised as Color::clamp does (draw/color.rs:148-155): `hsize*vsize*3` bytes.
     pub fn render_rgb8(&self, cam: &RtCamera, depth: i32) -> Vec<u8> {
         let mut rgb = vec![0u8; cam.hsize as usize * cam.vsize as usize * 3];
         let rc = unsafe {
-            rt_render(self.raw, cam, depth, RT_MODE_F64_PARITY, RT_PIPELINE_WAVEFRONT,
-                      std::ptr::null_mut(), rgb.as_mut_ptr(), std::ptr::null_mut())
+            if self.multi {
+                rt_render_multi(self.raw, cam, depth, RT_MODE_F64_PARITY, RT_PIPELINE_WAVEFRONT, rgb.as_mut_ptr(),
+                                std::ptr::null_mut(), std::ptr::null_mut())
+            } else {
+                rt_render(self.raw, cam, depth, RT_MODE_F64_PARITY, RT_PIPELINE_WAVEFRONT,
+                          std::ptr::null_mut(), rgb.as_mut_ptr(), std::ptr::null_mut())
+            }
         };
         if rc != 0 {
-            panic!("rt_render: {}", last_error());
+            panic!("render: {}", last_error());
         }
         rgb
     }

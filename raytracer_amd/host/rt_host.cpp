@@ -326,7 +326,7 @@ bool write_chunk(FILE* f, const Crc32& crc, const char type[4], const std::vecto
   std::vector<uint8_t> tail;
   put_be32(tail, c);
   return std::fwrite(head.data(), 1, head.size(), f) == head.size() &&
-         std::fwrite(data.data(), 1, data.size(), f) == data.size() &&
+         (data.empty() || std::fwrite(data.data(), 1, data.size(), f) == data.size()) &&  // IEND has no data
          std::fwrite(tail.data(), 1, tail.size(), f) == tail.size();
 }
 }  // namespace

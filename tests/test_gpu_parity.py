@@ -270,6 +270,35 @@ def test_cli_writes_the_reference_ppm(rt, O, tmp_path, pipeline):
     assert not np.array_equal(turn[1], ou8) and not np.array_equal(turn[2], turn[1])
 
 
+def test_plain_c_host_renders_the_default_world(rt, O, tmp_path, pipeline):
+    """tests/c_abi/cover.c — a C11 program built with gcc against include/rt_core.h — builds the
+    reference's default world (world.rs:180-204) through rt_scene_add_*, renders it with
+    rt_render; the frame it writes equals the oracle's."""
+    import os
+    import subprocess
+    import zlib
+    if pipeline != "wavefront":
+        pytest.skip("the C host names its pipeline itself")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(repo, "tests", "c_abi", "cover")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+    out = tmp_path / "cover.rgb"
+    r = subprocess.run([exe, str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = np.frombuffer(out.read_bytes(), dtype=np.uint8).reshape(64, 96, 3)
+    assert f"crc32={zlib.crc32(got.tobytes()):08x}" in r.stdout and "primitives=2" in r.stdout
+
+    def b(T, M, X):
+        scenes.populated_world(T, M, X)
+        T.set_camera(96, 64, math.pi / 3, X.view_transform((0, 0, -5), (0, 0, 0), (0, 1, 0)))
+    s = O.Scene()
+    b(s, O.material, rt)
+    _, ou8, cnt = s.render()
+    assert np.array_equal(got, ou8)
+    assert f"rays={cnt['primary'] + cnt['shadow'] + cnt['reflect'] + cnt['refract']} " in r.stdout
+
+
 def test_camera_sweep_equals_single_frames(rt, O, pipeline):
     """render_sequence (frames in flight on streams of the library's own, pinned copies back):
     every frame equals the one rendered alone, for new cameras and for cameras seen before."""

@@ -175,3 +175,67 @@ def test_png_writer_round_trip(rt, O, tmp_path, size):
     assert kinds == [b"IHDR", b"IDAT", b"IEND"] and pos == len(b)
     with pytest.raises(rt.RtError):
         rt.write_png(str(tmp_path / "no_such_dir" / "c.png"), rgb)
+
+
+# ---- every mirror of the C structs has the C compiler's layout ---------------------------------
+RUST_SIZES = {"f64": 8, "i64": 8, "u64": 8, "i32": 4, "u32": 4, "u8": 1}
+
+
+def rust_struct_sizes():
+    """Size and alignment of every #[repr(C)] struct of the Rust shim, by the C layout rules."""
+    import re
+    src = open(os.path.join(REPO, "integration", "rust", "src", "lib.rs")).read()
+    out = {}
+    for m in re.finditer(r"#\[repr\(C\)\](?:\s*#\[[^\]]*\])*\s*pub struct (\w+)\s*\{(.*?)\n\}", src, re.S):
+        off, align = 0, 1
+        for f in re.finditer(r"pub \w+:\s*([^,\n]+),", m.group(2)):
+            ty = f.group(1).strip()
+            arr = re.match(r"\[(\w+);\s*(\d+)\]", ty)
+            if arr:
+                size, al = RUST_SIZES[arr.group(1)] * int(arr.group(2)), RUST_SIZES[arr.group(1)]
+            elif ty.startswith("*"):
+                size = al = 8
+            else:
+                size = al = RUST_SIZES[ty]
+            off = (off + al - 1) // al * al + size
+            align = max(align, al)
+        out[m.group(1)] = (off + align - 1) // align * align
+    return out
+
+
+def test_every_mirror_has_the_c_layout(rt):
+    """tests/c_abi/sizes.c (gcc -std=c11 on include/rt_core.h) gives the truth; the ctypes
+    mirrors of the Python binding and the repr(C) mirrors of integration/rust must agree, struct
+    by struct."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "tests", "c_abi"), "sizes"])
+    c = dict(line.split() for line in subprocess.check_output(
+        [os.path.join(REPO, "tests", "c_abi", "sizes")], text=True).splitlines())
+    c = {k: int(v) for k, v in c.items()}
+    assert set(c) == {"rt_material", "rt_group", "rt_primitive", "rt_mesh", "rt_camera", "rt_stats", "rt_scene_info"}
+    rust = rust_struct_sizes()
+    pairs = {"rt_material": "RtMaterial", "rt_group": "RtGroup", "rt_primitive": "RtPrimitive", "rt_mesh": "RtMesh",
+             "rt_camera": "RtCamera", "rt_stats": "RtStats", "rt_scene_info": "RtSceneInfo"}
+    assert set(rust) == set(pairs.values())  # every repr(C) struct of the shim is named here
+    for cname, rname in pairs.items():
+        assert rust[rname] == c[cname], (cname, rust[rname], c[cname])
+    assert C.sizeof(rt.CameraABI) == c["rt_camera"]
+    assert C.sizeof(rt.Stats) == c["rt_stats"]
+    assert C.sizeof(rt.SceneInfo) == c["rt_scene_info"]
+
+
+def test_rust_shim_binds_every_core_entry_point():
+    """The extern block of the Rust shim names every function include/rt_core.h declares."""
+    import re
+    hdr = open(os.path.join(REPO, "include", "rt_core.h")).read()
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)))
+    src = open(os.path.join(REPO, "integration", "rust", "src", "lib.rs")).read()
+    bound = set(re.findall(r"pub fn (rt_[a-z0-9_]+)", src))
+    assert declared and declared <= bound, sorted(declared - bound)
+
+
+def test_plain_c_host_compiles():
+    """tests/c_abi/cover.c includes include/rt_core.h from C11 with -Wall -Wextra -Werror -pedantic."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "tests", "c_abi")])
+    assert os.path.exists(os.path.join(REPO, "tests", "c_abi", "cover"))
