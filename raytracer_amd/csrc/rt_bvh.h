@@ -25,10 +25,30 @@ struct BuildResult {
 void build_sah(const double* p1, const double* p2, const double* p3, int64_t n, int max_leaf,
                BuildResult& out);
 
-// The same result built on the current HIP device (Morton codes, radix sort, Karras' radix
-// tree, bottom-up refit): host arrays in, host vectors out.  Returns 0, or 1 with `err` set.
-int build_lbvh_device(const double* p1, const double* p2, const double* p3, int64_t n, int max_leaf,
-                      BuildResult& out, std::string& err);
+// A mesh's hierarchy built on the current HIP device (Morton codes, radix sort, Karras' radix
+// tree, bottom-up refit, fold into four-wide nodes breadth first) and left there: the wide nodes
+// with their child indices already offset by `node_base`, the triangle order, and the device
+// copies of the vertices that build_tri_records_device() turns into the triangle records.  Only
+// the mesh bounds and a few counts reach the host.  The caller owns the device pointers
+// (free_device_build).
+struct DeviceBuild {
+  rtd::DNode4* d_nodes = nullptr;
+  int n_nodes = 0;
+  int stack_need = 0;  // most stack entries a walk of the wide tree can hold
+  uint32_t* d_order = nullptr;
+  double *d_p1 = nullptr, *d_p2 = nullptr, *d_p3 = nullptr;
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, cell[3] = {0, 0, 0};
+  double scale = 0.0;
+};
+// Returns 0, or 1 with `err` set.
+int build_lbvh_resident(const double* p1, const double* p2, const double* p3, int64_t n, int max_leaf,
+                        int node_base, DeviceBuild& out, std::string& err);
+// Writes the n triangle records of the mesh (leaf order) straight into the scene's device tables.
+// n1,n2,n3,smooth: host arrays, or all null for a mesh of flat triangles.
+int build_tri_records_device(const DeviceBuild& b, int64_t n, const double* n1, const double* n2,
+                             const double* n3, const uint8_t* smooth, rtd::DTri* d_tris, rtd::DTriF* d_trisf,
+                             rtd::DTriN* d_trin, std::string& err);
+void free_device_build(DeviceBuild& b);
 
 // Folds a binary tree (nodes[0] = root) into four-wide nodes: the inner children of a binary
 // node are opened, largest surface first (cell = the mesh's grid steps), until four slots are

@@ -1112,111 +1112,177 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     M.pattern_kind = src.pattern_kind;
     M.pad[0] = M.pad[1] = M.pad[2] = 0;
   }
-  // meshes: edges (triangle.rs:49-51), BVH, records in leaf order
+  // meshes: edges (triangle.rs:49-51), BVH, records in leaf order.  The triangle tables are
+  // device arrays from the start: the host builder copies each mesh's records into its slice,
+  // the device builder writes them there itself (nothing of its tree or triangle order comes
+  // back to the host).
   std::vector<DMesh> meshes(s->meshes.size());
-  std::vector<DTri> tris;
-  std::vector<DTriF> trisf;
-  std::vector<DTriN> trin;
-  std::vector<DNode4> nodes;
   int64_t total_tris = 0;
   for (const MeshH& h : s->meshes) total_tris += h.ntris;
   if (total_tris > 0x7fffff00LL) return fail(RT_ERR_UNSUPPORTED, "too many triangles");
   for (const MeshH& h : s->meshes)
     if (h.ntris >= (1LL << (30 - LEAF_BITS)))
       return fail(RT_ERR_UNSUPPORTED, "too many triangles in one mesh for the leaf code");
-  tris.reserve((size_t)total_tris);
-  trin.reserve((size_t)total_tris);
+  s->info.device_bytes = 0;
+  auto device_table = [&](size_t bytes, void** out) -> int {
+    *out = nullptr;
+    HIP_TRY(hipMalloc(out, std::max<size_t>(bytes, 16)));
+    s->allocs.push_back(*out);
+    s->info.device_bytes += (int64_t)bytes;
+    return RT_OK;
+  };
+  DTri* d_tris = nullptr;
+  DTriF* d_trisf = nullptr;
+  DTriN* d_trin = nullptr;
+  int rc;
+  if ((rc = device_table((size_t)total_tris * sizeof(DTri), (void**)&d_tris))) return rc;
+  if ((rc = device_table((size_t)total_tris * sizeof(DTriF), (void**)&d_trisf))) return rc;
+  if ((rc = device_table((size_t)total_tris * sizeof(DTriN), (void**)&d_trin))) return rc;
+  struct MeshNodes {
+    std::vector<DNode4> host;  // host builder
+    rtb::DeviceBuild dev;      // device builder
+    int count = 0;
+  };
+  std::vector<MeshNodes> mesh_nodes(s->meshes.size());
+  struct FreeBuilds {  // whatever a device build still holds is released when commit ends
+    std::vector<MeshNodes>& v;
+    ~FreeBuilds() {
+      for (MeshNodes& m : v) rtb::free_device_build(m.dev);
+    }
+  } free_builds{mesh_nodes};
+  int64_t node_total = 0, tri_total = 0;
   for (size_t mi = 0; mi < s->meshes.size(); mi++) {
     const MeshH& h = s->meshes[mi];
-    rtb::BuildResult br;
     int max_leaf = 12;  // measured best with the shared leaf tests (pawn 1080p; 4..15 tried)
     if (const char* e = getenv("RT_MAX_LEAF")) max_leaf = atoi(e);
-    if (bvh_builder == 1) {
-      std::string berr;
-      if (rtb::build_lbvh_device(h.p1.data(), h.p2.data(), h.p3.data(), h.ntris, max_leaf, br, berr))
-        return fail(RT_ERR_HIP, "device BVH build: " + berr);
-    } else {
-      rtb::build_sah(h.p1.data(), h.p2.data(), h.p3.data(), h.ntris, max_leaf, br);
-    }
-    // the kernels walk four-wide nodes; a step leaves up to three children on the stack
-    std::vector<DNode4> wide;
-    const int stack_need = rtb::collapse_to_wide(br.nodes, br.cell, wide);
-    if (stack_need > STACK_MAX)
-      return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
-    rtb::reorder_top_breadth_first(wide, TOP_NODES);
     DMesh& M = meshes[mi];
     M.group = h.group;
     M.material = h.material;
     M.order_base = h.order_base;
-    M.root = (int32_t)nodes.size();
-    M.tri_base = (int32_t)tris.size();
+    M.root = (int32_t)node_total;
+    M.tri_base = (int32_t)tri_total;
     M.ntris = (int32_t)h.ntris;
-    M.n_nodes = (int32_t)wide.size();
     M.pad = 0;
-    for (int a = 0; a < 3; a++) {
-      M.lo[a] = br.lo[a];
-      M.hi[a] = br.hi[a];
-      M.cell[a] = br.cell[a];
-    }
-    M.scale = br.scale;
-    int32_t node_base = (int32_t)nodes.size();
-    for (DNode4 N : wide) {
-      for (int k = 0; k < 4; k++)
-        if (N.c[k] >= 0) N.c[k] += node_base;
-      nodes.push_back(N);
-    }
-    for (int64_t k = 0; k < h.ntris; k++) {
-      uint32_t f = br.order[k];
-      DTri T;
-      DTriN TN;
-      double e1[3], e2[3];
+    MeshNodes& mn = mesh_nodes[mi];
+    if (bvh_builder == 1) {
+      std::string berr;
+      if (rtb::build_lbvh_resident(h.p1.data(), h.p2.data(), h.p3.data(), h.ntris, max_leaf, (int)node_total, mn.dev,
+                                   berr))
+        return fail(RT_ERR_HIP, "device BVH build: " + berr);
+      if (mn.dev.stack_need > STACK_MAX) return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+      if (rtb::build_tri_records_device(mn.dev, h.ntris, h.has_normals ? h.n1.data() : nullptr,
+                                        h.has_normals ? h.n2.data() : nullptr, h.has_normals ? h.n3.data() : nullptr,
+                                        h.has_normals ? h.smooth.data() : nullptr, d_tris + tri_total,
+                                        d_trisf + tri_total, d_trin + tri_total, berr))
+        return fail(RT_ERR_HIP, "device triangle records: " + berr);
+      mn.count = mn.dev.n_nodes;
       for (int a = 0; a < 3; a++) {
-        T.p1[a] = h.p1[3 * f + a];
-        e1[a] = h.p2[3 * f + a] - h.p1[3 * f + a];
-        e2[a] = h.p3[3 * f + a] - h.p1[3 * f + a];
-        T.e1[a] = e1[a];
-        T.e2[a] = e2[a];
+        M.lo[a] = mn.dev.lo[a];
+        M.hi[a] = mn.dev.hi[a];
+        M.cell[a] = mn.dev.cell[a];
       }
-      T.orig = f;
-      T.smooth = h.smooth[f];
-      if (T.smooth) {
+      M.scale = mn.dev.scale;
+    } else {
+      rtb::BuildResult br;
+      rtb::build_sah(h.p1.data(), h.p2.data(), h.p3.data(), h.ntris, max_leaf, br);
+      // the kernels walk four-wide nodes; a step leaves up to three children on the stack
+      const int stack_need = rtb::collapse_to_wide(br.nodes, br.cell, mn.host);
+      if (stack_need > STACK_MAX) return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+      rtb::reorder_top_breadth_first(mn.host, TOP_NODES);
+      for (DNode4& N : mn.host)
+        for (int k = 0; k < 4; k++)
+          if (N.c[k] >= 0) N.c[k] += (int32_t)node_total;
+      mn.count = (int)mn.host.size();
+      for (int a = 0; a < 3; a++) {
+        M.lo[a] = br.lo[a];
+        M.hi[a] = br.hi[a];
+        M.cell[a] = br.cell[a];
+      }
+      M.scale = br.scale;
+      std::vector<DTri> tris((size_t)h.ntris);
+      std::vector<DTriF> trisf((size_t)h.ntris);
+      std::vector<DTriN> trin((size_t)h.ntris);
+      for (int64_t k = 0; k < h.ntris; k++) {
+        uint32_t f = br.order[k];
+        DTri T;
+        DTriN TN;
+        double e1[3], e2[3];
         for (int a = 0; a < 3; a++) {
-          TN.n[a] = h.n1[3 * f + a];
-          TN.n[3 + a] = h.n2[3 * f + a];
-          TN.n[6 + a] = h.n3[3 * f + a];
+          T.p1[a] = h.p1[3 * f + a];
+          e1[a] = h.p2[3 * f + a] - h.p1[3 * f + a];
+          e2[a] = h.p3[3 * f + a] - h.p1[3 * f + a];
+          T.e1[a] = e1[a];
+          T.e2[a] = e2[a];
         }
-      } else {
-        // triangle.rs:51: normalize(cross(e2, e1))
-        double cx = e2[1] * e1[2] - e2[2] * e1[1];
-        double cy = e2[2] * e1[0] - e2[0] * e1[2];
-        double cz = e2[0] * e1[1] - e2[1] * e1[0];
-        double mag = std::sqrt(cx * cx + cy * cy + cz * cz);
-        TN.n[0] = cx / mag;
-        TN.n[1] = cy / mag;
-        TN.n[2] = cz / mag;
-        for (int a = 3; a < 9; a++) TN.n[a] = 0.0;
+        T.orig = f;
+        T.smooth = h.smooth[f];
+        if (T.smooth) {
+          for (int a = 0; a < 3; a++) {
+            TN.n[a] = h.n1[3 * f + a];
+            TN.n[3 + a] = h.n2[3 * f + a];
+            TN.n[6 + a] = h.n3[3 * f + a];
+          }
+        } else {
+          // triangle.rs:51: normalize(cross(e2, e1))
+          double cx = e2[1] * e1[2] - e2[2] * e1[1];
+          double cy = e2[2] * e1[0] - e2[0] * e1[2];
+          double cz = e2[0] * e1[1] - e2[1] * e1[0];
+          double mag = std::sqrt(cx * cx + cy * cy + cz * cz);
+          TN.n[0] = cx / mag;
+          TN.n[1] = cy / mag;
+          TN.n[2] = cz / mag;
+          for (int a = 3; a < 9; a++) TN.n[a] = 0.0;
+        }
+        DTriF TF;
+        for (int a = 0; a < 3; a++) {
+          TF.p1[a] = (float)T.p1[a];
+          TF.e1[a] = (float)T.e1[a];
+          TF.e2[a] = (float)T.e2[a];
+        }
+        TF.orig = T.orig;
+        uint32_t lo16[3];
+        for (int a = 0; a < 3; a++) {
+          const float r = (float)(T.p1[a] - (double)TF.p1[a]);  // what f32 lost
+          uint32_t bits;
+          std::memcpy(&bits, &r, sizeof bits);
+          lo16[a] = bits >> 16;  // truncated: at most 2^-7 of the residual is dropped
+        }
+        TF.p1_lo_xy = lo16[0] | (lo16[1] << 16);
+        TF.p1_lo_z = lo16[2];
+        tris[(size_t)k] = T;
+        trisf[(size_t)k] = TF;
+        trin[(size_t)k] = TN;
       }
-      DTriF TF;
-      for (int a = 0; a < 3; a++) {
-        TF.p1[a] = (float)T.p1[a];
-        TF.e1[a] = (float)T.e1[a];
-        TF.e2[a] = (float)T.e2[a];
+      if (h.ntris > 0) {
+        HIP_TRY(hipMemcpy(d_tris + tri_total, tris.data(), tris.size() * sizeof(DTri), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_trisf + tri_total, trisf.data(), trisf.size() * sizeof(DTriF), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_trin + tri_total, trin.data(), trin.size() * sizeof(DTriN), hipMemcpyHostToDevice));
       }
-      TF.orig = T.orig;
-      uint32_t lo16[3];
-      for (int a = 0; a < 3; a++) {
-        const float r = (float)(T.p1[a] - (double)TF.p1[a]);  // what f32 lost
-        uint32_t bits;
-        std::memcpy(&bits, &r, sizeof bits);
-        lo16[a] = bits >> 16;  // truncated: at most 2^-7 of the residual is dropped
+    }
+    M.n_nodes = mn.count;
+    node_total += mn.count;
+    tri_total += h.ntris;
+  }
+  // the node table: every mesh's nodes back to back (indices were offset when they were made)
+  DNode4* d_nodes = nullptr;
+  if ((rc = device_table((size_t)node_total * sizeof(DNode4), (void**)&d_nodes))) return rc;
+  {
+    int64_t at = 0;
+    for (MeshNodes& mn : mesh_nodes) {
+      if (mn.count > 0) {
+        if (mn.dev.d_nodes)
+          HIP_TRY(hipMemcpy(d_nodes + at, mn.dev.d_nodes, (size_t)mn.count * sizeof(DNode4), hipMemcpyDeviceToDevice));
+        else
+          HIP_TRY(hipMemcpy(d_nodes + at, mn.host.data(), (size_t)mn.count * sizeof(DNode4), hipMemcpyHostToDevice));
       }
-      TF.p1_lo_xy = lo16[0] | (lo16[1] << 16);
-      TF.p1_lo_z = lo16[2];
-      tris.push_back(T);
-      trisf.push_back(TF);
-      trin.push_back(TN);
+      at += mn.count;
+      rtb::free_device_build(mn.dev);
     }
   }
+  s->d.tris = d_tris;
+  s->d.trisf = d_trisf;
+  s->d.trin = d_trin;
+  s->d.nodes = d_nodes;
 
   {
     // grid of the coherence sort: over the meshes' world-space bounds, or, in a scene without
@@ -1258,16 +1324,10 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     s->sort_enabled = s->sort_enabled && want_sort && atoi(want_sort) != 0;
     if (const char* e = getenv("RT_SORT_MIN_LEVEL")) s->sort_min_level = std::max(1, atoi(e));
   }
-  s->info.device_bytes = 0;
-  int rc;
   if ((rc = upload(s, groups, &s->d.groups))) return rc;
   if ((rc = upload(s, prims, &s->d.prims))) return rc;
   if ((rc = upload(s, prim_boxes, &s->d.prim_boxes))) return rc;
   if ((rc = upload(s, meshes, &s->d.meshes))) return rc;
-  if ((rc = upload(s, tris, &s->d.tris))) return rc;
-  if ((rc = upload(s, trisf, &s->d.trisf))) return rc;
-  if ((rc = upload(s, trin, &s->d.trin))) return rc;
-  if ((rc = upload(s, nodes, &s->d.nodes))) return rc;
   if ((rc = upload(s, mats, &s->d.mats))) return rc;
   if ((rc = upload(s, s->lights, &s->d.lights))) return rc;
   s->share_leaves = true;
@@ -1291,7 +1351,7 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   s->info.n_triangles = total_tris;
   s->info.n_materials = (int64_t)mats.size();
   s->info.n_lights = (int64_t)s->lights.size();
-  s->info.n_bvh_nodes = (int64_t)nodes.size();
+  s->info.n_bvh_nodes = node_total;
   s->info.node_bytes = (int32_t)sizeof(DNode4);
   s->info.tri_bytes = (int32_t)sizeof(DTri);
   s->info.device = device;

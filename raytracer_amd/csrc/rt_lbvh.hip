@@ -5,8 +5,12 @@
 //   triangle boxes + mesh bounds  ->  30-bit Morton code of each centroid
 //   ->  radix sort of (code << 32 | face)  ->  Karras' radix tree over the sorted keys
 //   ->  bottom-up refit  ->  collapse of subtrees with <= max_leaf triangles into leaves
-//   ->  nodes in the 32-byte layout of rt_layout.h (both children's boxes on the mesh's
-//       16-bit grid, rounded outward).
+//   ->  binary nodes (both children's boxes on the mesh's 16-bit grid, rounded outward)
+//   ->  four-wide nodes, level by level from the root (so the top of the tree comes first,
+//       breadth first), with the stack a walk can need
+//   ->  the triangle records (rt_layout.h) in leaf order.
+// Nothing of the tree or of the triangle order returns to the host: only the mesh bounds (56
+// bytes) and a few counts do.
 // Like the host builder it produces a pure culling structure; which triangle a ray hits is
 // decided by the exact test in rt_device.h.
 #include <hip/hip_runtime.h>
@@ -282,10 +286,145 @@ __global__ void k_extract_order(const unsigned long long* keys, int n, uint32_t*
   if (i < n) order[i] = (uint32_t)(keys[i] & 0xffffffffull);
 }
 
+// ---- four-wide nodes -------------------------------------------------------------------------
+// One entry of the breadth-first front: a binary node that becomes a wide node.
+struct WideTask {
+  int binary;  // index in the binary node array
+  int wide;    // position of the wide node (local to the mesh)
+  int above;   // stack entries the walk may hold when it arrives here
+};
+__device__ inline double slot_area(const uint32_t* q, const double* cell) {
+  double e[3];
+  for (int a = 0; a < 3; a++) {
+    const double lo = (double)(q[a] & 0xffffu), hi = (double)(q[a] >> 16);
+    e[a] = (hi > lo ? hi - lo : 0.0) * cell[a];
+  }
+  return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+}
+// One level of the fold: every front entry opens its binary node's inner children, largest
+// surface first, until four slots are taken (the rule of collapse_to_wide on the host), writes
+// its wide node and puts its inner slots on the next front.
+__global__ void k_wide_level(const rtd::DNode* bn, const WideTask* front, int n_front, WideTask* next,
+                             int* n_next, int* n_wide, int* max_need, GridD G, int node_base, rtd::DNode4* out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_front) return;
+  const WideTask w = front[t];
+  uint32_t q[4][3];
+  int code[4];
+  int n = 0;
+  auto add_children = [&](const rtd::DNode& N) {
+    const int cs[2] = {N.c0, N.c1};
+    for (int k = 0; k < 2; k++) {
+      if (cs[k] == -1) continue;
+      for (int a = 0; a < 3; a++) q[n][a] = N.q[3 * k + a];
+      code[n++] = cs[k];
+    }
+  };
+  add_children(bn[w.binary]);
+  while (n < 4) {
+    int best = -1;
+    double best_area = -1.0;
+    for (int k = 0; k < n; k++)
+      if (code[k] >= 0) {
+        const double area = slot_area(q[k], G.cell);
+        if (area > best_area) {
+          best_area = area;
+          best = k;
+        }
+      }
+    if (best < 0) break;
+    const rtd::DNode C = bn[code[best]];
+    const int kids = (C.c0 != -1) + (C.c1 != -1);
+    if (n - 1 + kids > 4) break;
+    n--;
+    for (int a = 0; a < 3; a++) q[best][a] = q[n][a];
+    code[best] = code[n];
+    add_children(C);
+  }
+  const int here = w.above + (n > 0 ? n - 1 : 0);  // while one child is walked the others wait on the stack
+  atomicMax(max_need, here);
+  rtd::DNode4 N;
+  for (int k = 0; k < 4; k++) {
+    if (k < n) {
+      for (int a = 0; a < 3; a++) N.q[3 * k + a] = q[k][a];
+      if (code[k] >= 0) {
+        const int child = atomicAdd(n_wide, 1);
+        N.c[k] = node_base + child;
+        next[atomicAdd(n_next, 1)] = WideTask{code[k], child, here};
+      } else {
+        N.c[k] = code[k];
+      }
+    } else {
+      for (int a = 0; a < 3; a++) N.q[3 * k + a] = 0xffffu;  // lo = 65535, hi = 0: never hit
+      N.c[k] = -1;
+    }
+  }
+  out[w.wide] = N;
+}
+
+// ---- triangle records --------------------------------------------------------------------------
+// Record k of the mesh is face order[k]: edges (triangle.rs:49-50), the flat normal
+// normalize(cross(e2, e1)) (triangle.rs:51) or the vertex normals, and the f32 copy of the fast
+// mode.  The same f64 operations the host path performs (this file is built without contraction).
+__global__ void k_tri_records(const double* p1, const double* p2, const double* p3, const double* n1,
+                              const double* n2, const double* n3, const uint8_t* smooth, const uint32_t* order,
+                              int n, rtd::DTri* tris, rtd::DTriF* trisf, rtd::DTriN* trin) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t f = order[k];
+  rtd::DTri T;
+  rtd::DTriN TN;
+  double e1[3], e2[3];
+  for (int a = 0; a < 3; a++) {
+    T.p1[a] = p1[3 * (size_t)f + a];
+    e1[a] = p2[3 * (size_t)f + a] - p1[3 * (size_t)f + a];
+    e2[a] = p3[3 * (size_t)f + a] - p1[3 * (size_t)f + a];
+    T.e1[a] = e1[a];
+    T.e2[a] = e2[a];
+  }
+  T.orig = f;
+  T.smooth = smooth ? smooth[f] : 0u;
+  if (T.smooth) {
+    for (int a = 0; a < 3; a++) {
+      TN.n[a] = n1[3 * (size_t)f + a];
+      TN.n[3 + a] = n2[3 * (size_t)f + a];
+      TN.n[6 + a] = n3[3 * (size_t)f + a];
+    }
+  } else {
+    const double cx = e2[1] * e1[2] - e2[2] * e1[1];
+    const double cy = e2[2] * e1[0] - e2[0] * e1[2];
+    const double cz = e2[0] * e1[1] - e2[1] * e1[0];
+    const double mag = sqrt(cx * cx + cy * cy + cz * cz);
+    TN.n[0] = cx / mag;
+    TN.n[1] = cy / mag;
+    TN.n[2] = cz / mag;
+    for (int a = 3; a < 9; a++) TN.n[a] = 0.0;
+  }
+  rtd::DTriF TF;
+  uint32_t lo16[3];
+  for (int a = 0; a < 3; a++) {
+    TF.p1[a] = (float)T.p1[a];
+    TF.e1[a] = (float)T.e1[a];
+    TF.e2[a] = (float)T.e2[a];
+    lo16[a] = __float_as_uint((float)(T.p1[a] - (double)TF.p1[a])) >> 16;
+  }
+  TF.orig = T.orig;
+  TF.p1_lo_xy = lo16[0] | (lo16[1] << 16);
+  TF.p1_lo_z = lo16[2];
+  tris[k] = T;
+  trisf[k] = TF;
+  trin[k] = TN;
+}
+
 struct Scratch {  // frees what it holds when the build ends, whichever way
   std::vector<void*> ptrs;
   ~Scratch() {
-    for (void* p : ptrs) (void)hipFree(p);
+    for (void* p : ptrs)
+      if (p) (void)hipFree(p);
+  }
+  void keep(void* p) {  // the caller takes this one over
+    for (void*& q : ptrs)
+      if (q == p) q = nullptr;
   }
   template <typename T>
   hipError_t get(T** p, size_t count) {
@@ -299,27 +438,39 @@ struct Scratch {  // frees what it holds when the build ends, whichever way
 
 }  // namespace
 
-int build_lbvh_device(const double* p1, const double* p2, const double* p3, int64_t n64, int max_leaf,
-                      BuildResult& out, std::string& err) {
-  out.nodes.clear();
-  out.order.clear();
-  out.max_depth = 0;
-  out.scale = 0.0;
-  for (int a = 0; a < 3; a++) out.lo[a] = out.hi[a] = out.cell[a] = 0.0;
+void free_device_build(DeviceBuild& b) {
+  void* ptrs[] = {b.d_nodes, b.d_order, b.d_p1, b.d_p2, b.d_p3};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  b.d_nodes = nullptr;
+  b.d_order = nullptr;
+  b.d_p1 = b.d_p2 = b.d_p3 = nullptr;
+}
+
+int build_lbvh_resident(const double* p1, const double* p2, const double* p3, int64_t n64, int max_leaf,
+                        int node_base, DeviceBuild& out, std::string& err) {
+  out = DeviceBuild();
   max_leaf = std::max(1, std::min(max_leaf, rtd::LEAF_MAX));
   if (n64 > (1 << (30 - rtd::LEAF_BITS))) {
     err = "mesh too large for the device builder";
     return 1;
   }
   const int n = (int)n64;
-  rtd::DNode empty{};
-  for (int k = 0; k < 6; k++) empty.q[k] = 0xffffu;
-  empty.c0 = empty.c1 = -1;
+  Scratch S;
+  rtd::DNode4 single;  // a mesh of no triangles, or of one leaf: one node, made here
+  for (int k = 0; k < 4; k++) {
+    for (int a = 0; a < 3; a++) single.q[3 * k + a] = 0xffffu;
+    single.c[k] = -1;
+  }
+  rtd::DNode4* d_wide = nullptr;
   if (n == 0) {
-    out.nodes.push_back(empty);
+    LB_TRY(S.get(&d_wide, 1));
+    LB_TRY(hipMemcpy(d_wide, &single, sizeof single, hipMemcpyHostToDevice));
+    S.keep(d_wide);
+    out.d_nodes = d_wide;
+    out.n_nodes = 1;
     return 0;
   }
-  Scratch S;
   double *d1, *d2, *d3;
   Box6* boxes;
   Bounds* bounds;
@@ -352,6 +503,8 @@ int build_lbvh_device(const double* p1, const double* p2, const double* p3, int6
   LB_TRY(S.get(&temp, temp_bytes));
   LB_TRY(hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys_in, keys, n, 0, 62));
 
+  // the mesh bounds come to the host (56 bytes): they size the node grid and go into the
+  // mesh's record
   Bounds hb;
   LB_TRY(hipMemcpy(&hb, bounds, sizeof hb, hipMemcpyDeviceToHost));
   out.scale = dec(hb.scale);
@@ -369,15 +522,28 @@ int build_lbvh_device(const double* p1, const double* p2, const double* p3, int6
   uint32_t* d_order;
   LB_TRY(S.get(&d_order, (size_t)n));
   hipLaunchKernelGGL(k_extract_order, grid, block, 0, 0, keys, n, d_order);
-  out.order.resize((size_t)n);
-  LB_TRY(hipMemcpy(out.order.data(), d_order, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  LB_TRY(hipGetLastError());
+  auto hand_over = [&]() {  // what the caller keeps: vertices and order for the record kernel
+    S.keep(d1);
+    S.keep(d2);
+    S.keep(d3);
+    S.keep(d_order);
+    out.d_p1 = d1;
+    out.d_p2 = d2;
+    out.d_p3 = d3;
+    out.d_order = d_order;
+  };
 
   if (n <= max_leaf) {  // the whole mesh is one leaf
-    rtd::DNode N = empty;
-    for (int a = 0; a < 3; a++) N.q[a] = 0u | (65535u << 16);
-    N.c0 = -2 - ((0 << rtd::LEAF_BITS) | n);
-    out.nodes.push_back(N);
-    out.max_depth = 1;
+    for (int a = 0; a < 3; a++) single.q[a] = 0u | (65535u << 16);
+    single.c[0] = -2 - ((0 << rtd::LEAF_BITS) | n);
+    LB_TRY(S.get(&d_wide, 1));
+    LB_TRY(hipMemcpy(d_wide, &single, sizeof single, hipMemcpyHostToDevice));
+    LB_TRY(hipDeviceSynchronize());
+    S.keep(d_wide);
+    out.d_nodes = d_wide;
+    out.n_nodes = 1;
+    hand_over();
     return 0;
   }
 
@@ -411,19 +577,73 @@ int build_lbvh_device(const double* p1, const double* p2, const double* p3, int6
   char* scan_temp;
   LB_TRY(S.get(&scan_temp, scan_bytes));
   LB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_temp, scan_bytes, live, new_index, n_inner));
-  int last_live = 0, last_index = 0, root_depth = 0;
+  int last_live = 0, last_index = 0;
   LB_TRY(hipMemcpy(&last_live, live + n_inner - 1, sizeof(int), hipMemcpyDeviceToHost));
   LB_TRY(hipMemcpy(&last_index, new_index + n_inner - 1, sizeof(int), hipMemcpyDeviceToHost));
-  LB_TRY(hipMemcpy(&root_depth, node_depth, sizeof(int), hipMemcpyDeviceToHost));
   const int n_live = last_index + last_live;
   rtd::DNode* d_nodes;
   LB_TRY(S.get(&d_nodes, (size_t)n_live));
   hipLaunchKernelGGL(k_emit_nodes, igrid, block, 0, 0, keys, boxes, child_l, child_r, range_first, range_last,
                      node_boxes, live, new_index, n_inner, max_leaf, G, d_nodes);
   LB_TRY(hipGetLastError());
-  out.nodes.resize((size_t)n_live);
-  LB_TRY(hipMemcpy(out.nodes.data(), d_nodes, (size_t)n_live * sizeof(rtd::DNode), hipMemcpyDeviceToHost));
-  out.max_depth = root_depth;
+
+  // fold into four-wide nodes, one level of the wide tree per launch, from the root (binary node
+  // 0 -> wide node 0); each level's length is the only thing the host reads
+  WideTask *front, *next;
+  int* counters;  // [0] entries on the next front, [1] wide nodes so far, [2] stack need
+  LB_TRY(S.get(&front, (size_t)n_live));
+  LB_TRY(S.get(&next, (size_t)n_live));
+  LB_TRY(S.get(&counters, 3));
+  LB_TRY(S.get(&d_wide, (size_t)n_live));
+  const WideTask root{0, 0, 0};
+  const int init3[3] = {0, 1, 0};
+  LB_TRY(hipMemcpy(front, &root, sizeof root, hipMemcpyHostToDevice));
+  LB_TRY(hipMemcpy(counters, init3, sizeof init3, hipMemcpyHostToDevice));
+  int n_front = 1, levels = 0;
+  while (n_front > 0) {
+    if (++levels > 4096) {
+      err = "wide collapse did not terminate";
+      return 1;
+    }
+    hipLaunchKernelGGL(k_wide_level, dim3((unsigned)((n_front + 127) / 128)), dim3(128), 0, 0, d_nodes, front, n_front,
+                       next, counters, counters + 1, counters + 2, G, node_base, d_wide);
+    LB_TRY(hipGetLastError());
+    LB_TRY(hipMemcpy(&n_front, counters, sizeof(int), hipMemcpyDeviceToHost));
+    LB_TRY(hipMemset(counters, 0, sizeof(int)));
+    std::swap(front, next);
+  }
+  int tail[2];
+  LB_TRY(hipMemcpy(tail, counters + 1, sizeof tail, hipMemcpyDeviceToHost));
+  S.keep(d_wide);
+  out.d_nodes = d_wide;
+  out.n_nodes = tail[0];
+  out.stack_need = tail[1];
+  hand_over();
+  return 0;
+}
+
+int build_tri_records_device(const DeviceBuild& b, int64_t n64, const double* n1, const double* n2,
+                             const double* n3, const uint8_t* smooth, rtd::DTri* d_tris, rtd::DTriF* d_trisf,
+                             rtd::DTriN* d_trin, std::string& err) {
+  const int n = (int)n64;
+  if (n == 0) return 0;
+  Scratch S;
+  double *dn1 = nullptr, *dn2 = nullptr, *dn3 = nullptr;
+  uint8_t* dsm = nullptr;
+  if (n1 && n2 && n3 && smooth) {
+    LB_TRY(S.get(&dn1, 3 * (size_t)n));
+    LB_TRY(S.get(&dn2, 3 * (size_t)n));
+    LB_TRY(S.get(&dn3, 3 * (size_t)n));
+    LB_TRY(S.get(&dsm, (size_t)n));
+    LB_TRY(hipMemcpy(dn1, n1, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    LB_TRY(hipMemcpy(dn2, n2, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    LB_TRY(hipMemcpy(dn3, n3, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    LB_TRY(hipMemcpy(dsm, smooth, (size_t)n, hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(k_tri_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, b.d_p1, b.d_p2, b.d_p3, dn1, dn2,
+                     dn3, dsm, b.d_order, n, d_tris, d_trisf, d_trin);
+  LB_TRY(hipGetLastError());
+  LB_TRY(hipDeviceSynchronize());
   return 0;
 }
 
