@@ -2,8 +2,9 @@
 //
 // Replaces the bounding-box tree of shapes/group.rs (the reference has none for its flat
 // child list, group.rs:64-71) with a linear BVH:
-//   triangle boxes + mesh bounds  ->  30-bit Morton code of each centroid
-//   ->  radix sort of (code << 32 | face)  ->  Karras' radix tree over the sorted keys
+//   triangle boxes + mesh bounds  ->  63-bit Morton code of each centroid (21 bits per axis)
+//   ->  radix sort of (code, face)  ->  Karras' radix tree over the sorted codes (equal codes are
+//       told apart by their position)
 //   ->  bottom-up refit  ->  collapse of subtrees with <= max_leaf triangles into leaves
 //   ->  binary nodes (both children's boxes on the mesh's 16-bit grid, rounded outward)
 //   ->  four-wide nodes, level by level from the root (so the top of the tree comes first,
@@ -19,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -96,40 +98,44 @@ __global__ void k_tri_bounds(const double* p1, const double* p2, const double* p
   }
 }
 
-__device__ inline unsigned expand10(unsigned v) {  // 10 bits -> every third bit
-  v = (v * 0x00010001u) & 0xFF0000FFu;
-  v = (v * 0x00000101u) & 0x0F00F00Fu;
-  v = (v * 0x00000011u) & 0xC30C30C3u;
-  v = (v * 0x00000005u) & 0x49249249u;
-  return v;
+__device__ inline unsigned long long expand21(unsigned long long x) {  // 21 bits -> every third bit
+  x &= 0x1fffffull;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
 }
 
-__global__ void k_morton(const Box6* boxes, int n, const Bounds* bounds, unsigned long long* keys) {
+__global__ void k_morton(const Box6* boxes, int n, const Bounds* bounds, unsigned long long* keys, uint32_t* faces) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  unsigned q[3];
+  unsigned long long q[3];
   for (int a = 0; a < 3; a++) {
     double lo = dec(bounds->lo[a]), hi = dec(bounds->hi[a]);
     double c = 0.5 * (boxes[t].lo[a] + boxes[t].hi[a]);
     double ext = hi - lo;
     double x = ext > 0.0 ? (c - lo) / ext : 0.0;
-    int v = (int)(x * 1024.0);
-    q[a] = (unsigned)min(max(v, 0), 1023);
+    long long v = (long long)(x * 2097152.0);
+    q[a] = (unsigned long long)min(max(v, 0ll), 2097151ll);
   }
-  unsigned code = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
-  keys[t] = ((unsigned long long)code << 32) | (unsigned)t;
+  keys[t] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+  faces[t] = (uint32_t)t;
 }
 
 constexpr int LEAF_BIT = 0x40000000;
 
-// Karras 2012: internal node i of the radix tree over n sorted, distinct keys.
+// Karras 2012: internal node i of the radix tree over n sorted keys; equal keys are ordered by
+// their position (64 + the common prefix of the positions), which keeps the keys distinct.
 __global__ void k_radix_tree(const unsigned long long* keys, int n, int* child_l, int* child_r,
                              int* range_first, int* range_last, int* parent_inner, int* parent_leaf) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n - 1) return;
   auto delta = [&](int a, int b) -> int {
     if (b < 0 || b >= n) return -1;
-    return __clzll((long long)(keys[a] ^ keys[b]));
+    const unsigned long long x = keys[a] ^ keys[b];
+    return x ? __clzll((long long)x) : 64 + __clz(a ^ b);
   };
   int d = (delta(i, i + 1) - delta(i, i - 1)) >= 0 ? 1 : -1;
   int dmin = delta(i, i - d);
@@ -178,9 +184,10 @@ __device__ inline void box_load(const double* src, double* dst) {
 }
 
 // One thread per leaf walks towards the root; the second thread to reach a node owns it.
-__global__ void k_refit(const unsigned long long* keys, const Box6* tri_boxes, int n, const int* child_l,
+__global__ void k_refit(const uint32_t* faces, const Box6* tri_boxes, int n, const int* child_l,
                         const int* child_r, const int* parent_inner, const int* parent_leaf,
-                        unsigned int* arrivals, double* node_boxes, int* node_depth) {
+                        unsigned int* arrivals, double* node_boxes, int* node_depth, const int* range_first,
+                        const int* range_last, int max_leaf, float trav_cost, float* node_cost, int* leafify) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   int node = parent_leaf[k];
@@ -193,11 +200,14 @@ __global__ void k_refit(const unsigned long long* keys, const Box6* tri_boxes, i
                    -__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val()};
     int depth = 0;
     const int cs[2] = {child_l[node], child_r[node]};
+    double child_area[2];
+    float child_cost[2];
     for (int w = 0; w < 2; w++) {
       double cb[6];
       int cd = 0;
+      child_cost[w] = 1.0f;  // one triangle test
       if (cs[w] & LEAF_BIT) {
-        const Box6& tb = tri_boxes[(unsigned)(keys[cs[w] & ~LEAF_BIT] & 0xffffffffull)];
+        const Box6& tb = tri_boxes[faces[cs[w] & ~LEAF_BIT]];
         for (int a = 0; a < 3; a++) {
           cb[a] = tb.lo[a];
           cb[3 + a] = tb.hi[a];
@@ -205,12 +215,29 @@ __global__ void k_refit(const unsigned long long* keys, const Box6* tri_boxes, i
       } else {
         box_load(node_boxes + 6 * (size_t)cs[w], cb);
         cd = __hip_atomic_load(node_depth + cs[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        child_cost[w] = __hip_atomic_load(node_cost + cs[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       for (int a = 0; a < 3; a++) {
         b[a] = fmin(b[a], cb[a]);
         b[3 + a] = fmax(b[3 + a], cb[3 + a]);
       }
+      const double ex = cb[3] - cb[0], ey = cb[4] - cb[1], ez = cb[5] - cb[2];
+      child_area[w] = ex * ey + ey * ez + ez * ex;
       depth = max(depth, cd);
+    }
+    // Surface-area heuristic, bottom up: this subtree as ONE leaf costs its triangle count;
+    // split, it costs a node step plus each child's cost weighted by the chance that a ray
+    // which meets this box meets the child's.  Small subtrees take the cheaper of the two.
+    {
+      const double ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
+      const double area = ex * ey + ey * ez + ez * ex;
+      const float w0 = area > 0.0 ? (float)fmin(child_area[0] / area, 1.0) : 1.0f;
+      const float w1 = area > 0.0 ? (float)fmin(child_area[1] / area, 1.0) : 1.0f;
+      const float split = trav_cost + w0 * child_cost[0] + w1 * child_cost[1];
+      const int count = range_last[node] - range_first[node] + 1;
+      const bool as_leaf = count <= max_leaf && (float)count <= split;
+      leafify[node] = as_leaf ? 1 : 0;
+      __hip_atomic_store(node_cost + node, as_leaf ? (float)count : split, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     box_store(node_boxes + 6 * (size_t)node, b);
     __hip_atomic_store(node_depth + node, depth + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -218,11 +245,20 @@ __global__ void k_refit(const unsigned long long* keys, const Box6* tri_boxes, i
   }
 }
 
-__global__ void k_mark_live(const int* range_first, const int* range_last, int n_inner, int max_leaf,
-                            int* live) {
+// An inner node stays unless it, or one of its ancestors, became a leaf.  Only subtrees of at
+// most max_leaf triangles can be leaves, so the walk up ends at the first larger ancestor.  The
+// root always stays.
+__global__ void k_mark_live(const int* range_first, const int* range_last, const int* parent_inner,
+                            const int* leafify, int n_inner, int max_leaf, int* live) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_inner) return;
-  live[i] = (i == 0 || (range_last[i] - range_first[i] + 1) > max_leaf) ? 1 : 0;
+  int alive = 1;
+  for (int a = i; a > 0 && (range_last[a] - range_first[a] + 1) <= max_leaf; a = parent_inner[a])
+    if (leafify[a]) {
+      alive = 0;
+      break;
+    }
+  live[i] = alive;
 }
 
 struct GridD {
@@ -247,9 +283,9 @@ __device__ inline unsigned grid_up(const GridD& G, int a, double x) {
   return k;
 }
 
-__global__ void k_emit_nodes(const unsigned long long* keys, const Box6* tri_boxes, const int* child_l,
+__global__ void k_emit_nodes(const uint32_t* faces, const Box6* tri_boxes, const int* child_l,
                              const int* child_r, const int* range_first, const int* range_last,
-                             const double* node_boxes, const int* live, const int* new_index,
+                             const double* node_boxes, const int* live, const int* new_index, const int* leafify,
                              int n_inner, int max_leaf, GridD G, rtd::DNode* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_inner || !live[i]) return;
@@ -260,7 +296,7 @@ __global__ void k_emit_nodes(const unsigned long long* keys, const Box6* tri_box
     int code;
     if (cs[w] & LEAF_BIT) {
       int pos = cs[w] & ~LEAF_BIT;
-      const Box6& tb = tri_boxes[(unsigned)(keys[pos] & 0xffffffffull)];
+      const Box6& tb = tri_boxes[faces[pos]];
       for (int a = 0; a < 3; a++) {
         b[a] = tb.lo[a];
         b[3 + a] = tb.hi[a];
@@ -270,7 +306,7 @@ __global__ void k_emit_nodes(const unsigned long long* keys, const Box6* tri_box
       int c = cs[w];
       for (int k = 0; k < 6; k++) b[k] = node_boxes[6 * (size_t)c + k];
       int cnt = range_last[c] - range_first[c] + 1;
-      code = (cnt <= max_leaf) ? -2 - ((range_first[c] << rtd::LEAF_BITS) | cnt) : new_index[c];
+      code = (cnt <= max_leaf && leafify[c]) ? -2 - ((range_first[c] << rtd::LEAF_BITS) | cnt) : new_index[c];
     }
     for (int a = 0; a < 3; a++) {
       unsigned lo = grid_down(G, a, b[a] - G.pad), hi = grid_up(G, a, b[3 + a] + G.pad);
@@ -279,11 +315,6 @@ __global__ void k_emit_nodes(const unsigned long long* keys, const Box6* tri_box
     (w == 0 ? N.c0 : N.c1) = code;
   }
   out[new_index[i]] = N;
-}
-
-__global__ void k_extract_order(const unsigned long long* keys, int n, uint32_t* order) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) order[i] = (uint32_t)(keys[i] & 0xffffffffull);
 }
 
 // ---- four-wide nodes -------------------------------------------------------------------------
@@ -475,6 +506,9 @@ int build_lbvh_resident(const double* p1, const double* p2, const double* p3, in
   Box6* boxes;
   Bounds* bounds;
   unsigned long long *keys_in, *keys;
+  uint32_t *faces_in, *d_order;  // d_order: face of the k-th triangle in Morton order
+  LB_TRY(S.get(&faces_in, (size_t)n));
+  LB_TRY(S.get(&d_order, (size_t)n));
   LB_TRY(S.get(&d1, 3 * (size_t)n));
   LB_TRY(S.get(&d2, 3 * (size_t)n));
   LB_TRY(S.get(&d3, 3 * (size_t)n));
@@ -495,13 +529,13 @@ int build_lbvh_resident(const double* p1, const double* p2, const double* p3, in
   LB_TRY(hipMemcpy(bounds, &init, sizeof init, hipMemcpyHostToDevice));
   const dim3 block(256), grid((unsigned)((n + 255) / 256));
   hipLaunchKernelGGL(k_tri_bounds, grid, block, 0, 0, d1, d2, d3, n, boxes, bounds);
-  hipLaunchKernelGGL(k_morton, grid, block, 0, 0, boxes, n, bounds, keys_in);
+  hipLaunchKernelGGL(k_morton, grid, block, 0, 0, boxes, n, bounds, keys_in, faces_in);
   LB_TRY(hipGetLastError());
   size_t temp_bytes = 0;
-  LB_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys_in, keys, n, 0, 62));
+  LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in, keys, faces_in, d_order, n, 0, 63));
   char* temp;
   LB_TRY(S.get(&temp, temp_bytes));
-  LB_TRY(hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys_in, keys, n, 0, 62));
+  LB_TRY(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys, faces_in, d_order, n, 0, 63));
 
   // the mesh bounds come to the host (56 bytes): they size the node grid and go into the
   // mesh's record
@@ -519,10 +553,6 @@ int build_lbvh_resident(const double* p1, const double* p2, const double* p3, in
     out.hi[a] = std::max(hi, lo + 65535.0 * G.cell[a]);
     out.cell[a] = G.cell[a];
   }
-  uint32_t* d_order;
-  LB_TRY(S.get(&d_order, (size_t)n));
-  hipLaunchKernelGGL(k_extract_order, grid, block, 0, 0, keys, n, d_order);
-  LB_TRY(hipGetLastError());
   auto hand_over = [&]() {  // what the caller keeps: vertices and order for the record kernel
     S.keep(d1);
     S.keep(d2);
@@ -552,6 +582,13 @@ int build_lbvh_resident(const double* p1, const double* p2, const double* p3, in
       *new_index;
   unsigned int* arrivals;
   double* node_boxes;
+  float* node_cost;
+  int* leafify;
+  LB_TRY(S.get(&node_cost, (size_t)n_inner));
+  LB_TRY(S.get(&leafify, (size_t)n_inner));
+  LB_TRY(hipMemset(leafify, 0, (size_t)n_inner * sizeof(int)));
+  float trav_cost = 1.5f;  // cost of a step down the binary tree, in triangle tests
+  if (const char* e = getenv("RT_LBVH_TRAV")) trav_cost = (float)atof(e);
   LB_TRY(S.get(&child_l, (size_t)n_inner));
   LB_TRY(S.get(&child_r, (size_t)n_inner));
   LB_TRY(S.get(&range_first, (size_t)n_inner));
@@ -568,9 +605,10 @@ int build_lbvh_resident(const double* p1, const double* p2, const double* p3, in
   const dim3 igrid((unsigned)((n_inner + 255) / 256));
   hipLaunchKernelGGL(k_radix_tree, igrid, block, 0, 0, keys, n, child_l, child_r, range_first, range_last,
                      parent_inner, parent_leaf);
-  hipLaunchKernelGGL(k_refit, grid, block, 0, 0, keys, boxes, n, child_l, child_r, parent_inner, parent_leaf,
-                     arrivals, node_boxes, node_depth);
-  hipLaunchKernelGGL(k_mark_live, igrid, block, 0, 0, range_first, range_last, n_inner, max_leaf, live);
+  hipLaunchKernelGGL(k_refit, grid, block, 0, 0, d_order, boxes, n, child_l, child_r, parent_inner, parent_leaf,
+                     arrivals, node_boxes, node_depth, range_first, range_last, max_leaf, trav_cost, node_cost, leafify);
+  hipLaunchKernelGGL(k_mark_live, igrid, block, 0, 0, range_first, range_last, parent_inner, leafify, n_inner, max_leaf,
+                     live);
   LB_TRY(hipGetLastError());
   size_t scan_bytes = 0;
   LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, live, new_index, n_inner));
@@ -583,8 +621,8 @@ int build_lbvh_resident(const double* p1, const double* p2, const double* p3, in
   const int n_live = last_index + last_live;
   rtd::DNode* d_nodes;
   LB_TRY(S.get(&d_nodes, (size_t)n_live));
-  hipLaunchKernelGGL(k_emit_nodes, igrid, block, 0, 0, keys, boxes, child_l, child_r, range_first, range_last,
-                     node_boxes, live, new_index, n_inner, max_leaf, G, d_nodes);
+  hipLaunchKernelGGL(k_emit_nodes, igrid, block, 0, 0, d_order, boxes, child_l, child_r, range_first, range_last,
+                     node_boxes, live, new_index, leafify, n_inner, max_leaf, G, d_nodes);
   LB_TRY(hipGetLastError());
 
   // fold into four-wide nodes, one level of the wide tree per launch, from the root (binary node
