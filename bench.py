@@ -152,7 +152,8 @@ def main():
     ap.add_argument("--hw-queues", type=int, default=8,
                     help="GPU_MAX_HW_QUEUES for this process (HIP's default is 4: more frames in flight than "
                          "hardware queues share queues and serialise); 0 leaves the environment as it is")
-    ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="host binned-SAH or device LBVH build")
+    ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh", "auto"],
+                    help="host binned-SAH build, device LBVH build, or by mesh size (device from 100k triangles on)")
     ap.add_argument("--sustain-s", type=float, default=1.0,
                     help="after the timed steps, the same loop again for at least this long (0 = skip)")
     ap.add_argument("--cpu-pixels", type=int, default=16384)
@@ -202,7 +203,7 @@ def main():
     pipeline = {"megakernel": rt.PIPELINE_MEGAKERNEL, "wavefront": rt.PIPELINE_WAVEFRONT,
                 "auto": rt.PIPELINE_AUTO}[args.pipeline]
     mode = rt.MODE_F32_FAST if args.mode == "f32_fast" else rt.MODE_F64_PARITY
-    w = rt.World.example(example, hs, vs, synthetic_tris=ntris).commit(device=dev.index, bvh_builder=1 if args.bvh == "lbvh" else 0)
+    w = rt.World.example(example, hs, vs, synthetic_tris=ntris).commit(device=dev.index, bvh_builder={"sah": 0, "lbvh": 1, "auto": 2}[args.bvh])
     info = w.info()
     F = max(1, args.inflight)
     streams = [torch.cuda.Stream(device=dev) for _ in range(F)]

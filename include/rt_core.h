@@ -151,7 +151,7 @@ typedef struct rt_scene_info {
   int32_t node_bytes; /* size of one BVH node record */
   int32_t tri_bytes;  /* size of one triangle record read by the intersection test */
   int32_t device;
-  int32_t bvh_builder; /* 0 host SAH, 1 device LBVH */
+  int32_t bvh_builder; /* as given to rt_scene_commit */
   double commit_ms;
 } rt_scene_info;
 
@@ -170,8 +170,10 @@ int rt_scene_add_mesh(rt_scene*, const rt_mesh*);
 int rt_scene_add_light(rt_scene*, const double intensity[3], const double position[3]);
 
 /* Builds the per-mesh BVHs and uploads everything to `device` (-1: current device).
- * bvh_builder: 0 = host binned-SAH build, 1 = device LBVH build.  After commit the
- * scene is immutable. */
+ * bvh_builder: 0 = host binned-SAH build, 1 = device LBVH build (Morton codes, radix tree, fold
+ * into four-wide nodes and triangle records all on the GPU), 2 = by mesh size (device build from
+ * 100 000 triangles on).  Frames are the same bits with any of them.  After commit the scene is
+ * immutable. */
 int rt_scene_commit(rt_scene*, int device, int bvh_builder);
 int rt_scene_get_info(const rt_scene*, rt_scene_info*);
 

@@ -1049,7 +1049,8 @@ int rt_scene_add_light(rt_scene* s, const double intensity[3], const double posi
 int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   if (!s) return fail(RT_ERR_ARG, "null scene");
   if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
-  if (bvh_builder != 0 && bvh_builder != 1) return fail(RT_ERR_ARG, "bvh_builder must be 0 (host SAH) or 1 (device LBVH)");
+  if (bvh_builder < 0 || bvh_builder > 2)
+    return fail(RT_ERR_ARG, "bvh_builder must be 0 (host SAH), 1 (device LBVH) or 2 (by mesh size)");
   int ndev = rt_device_count();
   if (ndev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible; the render core has no CPU path");
   if (device < 0) HIP_TRY(hipGetDevice(&device));
@@ -1164,7 +1165,11 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     M.ntris = (int32_t)h.ntris;
     M.pad = 0;
     MeshNodes& mn = mesh_nodes[mi];
-    if (bvh_builder == 1) {
+    // 2: the host's binned SAH gives small meshes slightly faster frames (pawn: 8 %) for a few
+    // milliseconds of build; from 100 000 triangles on the device build wins on every count
+    // (1M triangles: 21 ms instead of 0.9 s, frames within 2 %)
+    const bool on_device = bvh_builder == 1 || (bvh_builder == 2 && h.ntris >= 100000);
+    if (on_device) {
       std::string berr;
       if (rtb::build_lbvh_resident(h.p1.data(), h.p2.data(), h.p3.data(), h.ntris, max_leaf, (int)node_total, mn.dev,
                                    berr))

@@ -171,6 +171,23 @@ def test_device_built_bvh(rt, O, name, size, ntris):
     assert sb.rays_shadow == cnt["shadow"]
 
 
+def test_bvh_builder_by_mesh_size(rt, O):
+    """bvh_builder=2: meshes of 100 000 triangles and more are built on the device, smaller ones
+    on the host; the frame is the host build's."""
+    n = 120000
+    a = rt.World.example("synthetic", 240, 135, synthetic_tris=n).commit(bvh_builder=0)
+    b = rt.World.example("synthetic", 240, 135, synthetic_tris=n).commit(bvh_builder=2)
+    assert b.info()["bvh_builder"] == 2 and b.info()["n_bvh_nodes"] != a.info()["n_bvh_nodes"]
+    ua, fa, _ = a.render(want_f64=True)
+    ub, fb, _ = b.render(want_f64=True)
+    assert np.array_equal(ua, ub) and np.array_equal(fa, fb)
+    c = rt.World.example("pawn", 96, 54).commit(bvh_builder=2)  # 31 776 triangles: host build
+    d = rt.World.example("pawn", 96, 54).commit(bvh_builder=0)
+    assert c.info()["n_bvh_nodes"] == d.info()["n_bvh_nodes"]
+    with pytest.raises(rt.RtError):
+        rt.World.example("cover", 16, 16).commit(bvh_builder=3)
+
+
 @pytest.mark.parametrize("name,size,ntris", [("pawn", (1920, 1080), 0), ("tea set", (1920, 1080), 0),
                                              ("cover", (400, 400), 0), ("synthetic", (960, 540), 200000)])
 def test_f32_fast_mode_meets_the_stated_tolerance(rt, O, name, size, ntris, pipeline):
