@@ -17,4 +17,4 @@ names = ["task load / ray generation", "closest-hit traversal", "prepare, patter
          "predecessor traversal", "containers, optics, emit, node write"]
 tot = sum(out[:6])
 for n, v in zip(names, out):
-    print(f"{n:40s} {100.0 * v / tot:5.1f} %")
+    print(f"{n:40s} {100.0 * v / tot:5.1f} %  {v / 1e6:10.1f} Mcycles")
