@@ -146,12 +146,15 @@ def main():
     ap.add_argument("--pipeline", default="wavefront", choices=["megakernel", "wavefront", "auto"])
     ap.add_argument("--mode", default="f64_parity", choices=["f64_parity", "f32_fast"],
                     help="f32_fast: triangle search in f32, everything else f64; reported with its pixel-match rate")
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight: step k is issued on stream k %% inflight with its own buffers, so the "
-                         "tail of one frame's recursion level runs under the next frame (1 = strictly one at a time)")
-    ap.add_argument("--hw-queues", type=int, default=8,
+                         "tail of one frame's recursion level runs under the next frame (1 = strictly one at a time; "
+                         "0 = 4 on one GPU, 8 per rank on several: a rank's share of the frame fills its GPU only "
+                         "together with its neighbours)")
+    ap.add_argument("--hw-queues", type=int, default=-1,
                     help="GPU_MAX_HW_QUEUES for this process (HIP's default is 4: more frames in flight than "
-                         "hardware queues share queues and serialise); 0 leaves the environment as it is")
+                         "hardware queues share queues and serialise); 0 leaves the environment as it is; "
+                         "-1 = 8 on one GPU, 12 per rank on several (the exchange has a stream of its own)")
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh", "auto"],
                     help="host binned-SAH build, device LBVH build, or by mesh size (device from 100k triangles on)")
     ap.add_argument("--sustain-s", type=float, default=1.0,
@@ -159,6 +162,10 @@ def main():
     ap.add_argument("--cpu-pixels", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.inflight <= 0:
+        args.inflight = 4 if args.gpus == 1 else 8
+    if args.hw_queues < 0:
+        args.hw_queues = 8 if args.gpus == 1 else 12
     if args.hw_queues > 0:  # read by the HIP runtime when it starts: set before anything touches the GPU
         os.environ["GPU_MAX_HW_QUEUES"] = str(min(args.hw_queues, 32))
 
