@@ -219,7 +219,9 @@ int rt_detile_u8(const uint8_t* d_tiles, int nshards, int64_t tiles_per_shard, i
  * device_ids[0]); at least one must be given.  The image is the one rt_render produces, byte for
  * byte, for every ndev; ndev = 1 runs the same steps (its shard goes through RCCL to itself).
  * stats (may be NULL): counters summed over the GPUs, kernel_ms the slowest GPU's.
- * One host thread per scene; the call returns when the image is complete. */
+ * One host thread per scene; the call returns when the image is complete.  A scene whose
+ * rt_scene_commit_multi failed can only be destroyed (rt_render_multi refuses it).  Both calls
+ * leave the caller's current HIP device as they found it. */
 int rt_scene_commit_multi(rt_scene*, const int* device_ids, int ndev, int bvh_builder);
 int rt_render_multi(rt_scene*, const rt_camera*, int depth, int mode, int pipeline,
                     uint8_t* out_rgb_u8, uint8_t* d_rgb_u8, rt_stats* stats);

@@ -1861,12 +1861,15 @@ static size_t noalloc_layout(long long px, int depth, NoallocLayout& L) {
 int64_t rt_noalloc_max_tiles(int depth) {
   if (depth < 0 || depth > MAX_DEPTH) return -1;
   NoallocLayout L;
-  int64_t best = 0;
-  for (int64_t t = 1; t <= RT_NOALLOC_MAX_TILES; t++) {
-    if (noalloc_layout(t * (RT_TILE * RT_TILE), depth, L) > (size_t)RT_NOALLOC_SCRATCH_BYTES) break;
-    best = t;
+  int64_t fits = 0, over = RT_NOALLOC_MAX_TILES + 1;  // the layout grows with the tile count: bisect
+  while (over - fits > 1) {
+    const int64_t t = fits + (over - fits) / 2;
+    if (noalloc_layout(t * (RT_TILE * RT_TILE), depth, L) > (size_t)RT_NOALLOC_SCRATCH_BYTES)
+      over = t;
+    else
+      fits = t;
   }
-  return best;
+  return fits;
 }
 
 int rt_render_device_noalloc(rt_scene* s, const rt_camera* cam, int depth, int mode, int tile_first,
@@ -2224,6 +2227,19 @@ struct Multi {
   size_t all_cap = 0;
   uint8_t* d_image = nullptr;     // first GPU: the stitched image, when the caller gave no device buffer
   size_t image_cap = 0;
+  bool ready = false;             // rt_scene_commit_multi ran to its end
+};
+
+// Puts the caller's current device back when an entry point that visits several GPUs returns,
+// whichever way it returns.
+struct CurrentDeviceKeeper {
+  int device = -1;
+  CurrentDeviceKeeper() {
+    if (hipGetDevice(&device) != hipSuccess) device = -1;
+  }
+  ~CurrentDeviceKeeper() {
+    if (device >= 0) (void)hipSetDevice(device);
+  }
 };
 
 static void multi_destroy(Multi* m) {
@@ -2258,8 +2274,7 @@ int rt_scene_commit_multi(rt_scene* s, const int* device_ids, int ndev, int bvh_
   }
   int rc = rccl_load();
   if (rc) return rc;
-  int previous = 0;
-  HIP_TRY(hipGetDevice(&previous));
+  CurrentDeviceKeeper keep;
   Multi* m = new Multi;
   m->devs.assign(device_ids, device_ids + ndev);
   m->scenes.assign((size_t)ndev, nullptr);
@@ -2292,26 +2307,27 @@ int rt_scene_commit_multi(rt_scene* s, const int* device_ids, int ndev, int bvh_
     HIP_TRY(hipSetDevice(m->devs[(size_t)d]));
     HIP_TRY(hipStreamCreateWithFlags(&m->streams[(size_t)d], hipStreamNonBlocking));
   }
-  HIP_TRY(hipSetDevice(previous));
+  m->ready = true;
   return RT_OK;
 }
 
 int rt_scene_device_count(const rt_scene* s) {
   if (!s || !s->committed) return 0;
+  if (s->multi && !s->multi->ready) return 0;  // a multi-GPU commit that failed half way: only destroy is left
   return s->multi ? (int)s->multi->devs.size() : 1;
 }
 
 int rt_render_multi(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline, uint8_t* out_rgb_u8,
                     uint8_t* d_rgb_u8, rt_stats* stats) {
   if (!s || !cam) return fail(RT_ERR_ARG, "null argument");
-  if (!s->committed || !s->multi) return fail(RT_ERR_STATE, "scene not committed with rt_scene_commit_multi");
+  if (!s->committed || !s->multi || !s->multi->ready)
+    return fail(RT_ERR_STATE, "scene not committed with rt_scene_commit_multi (or that commit failed)");
   if (cam->hsize <= 0 || cam->vsize <= 0) return fail(RT_ERR_ARG, "camera size must be positive");
   if (!out_rgb_u8 && !d_rgb_u8) return fail(RT_ERR_ARG, "no output buffer");
   Multi* m = s->multi;
   const int ndev = (int)m->devs.size();
   auto t0 = std::chrono::steady_clock::now();
-  int previous = 0;
-  HIP_TRY(hipGetDevice(&previous));
+  CurrentDeviceKeeper keep;
   int64_t per = 0;
   for (int d = 0; d < ndev; d++) per = std::max(per, rt_shard_tiles(cam->hsize, cam->vsize, d, ndev));
   const size_t bytes_per = (size_t)per * RT_TILE * RT_TILE * 3;
@@ -2400,7 +2416,6 @@ int rt_render_multi(rt_scene* s, const rt_camera* cam, int depth, int mode, int 
     }
     stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
-  HIP_TRY(hipSetDevice(previous));
   return RT_OK;
 }
 
