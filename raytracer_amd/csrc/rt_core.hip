@@ -669,13 +669,22 @@ __device__ __forceinline__ bool emit_result(const ShadeOut& so, const C3& surfac
 #ifdef RT_SECTION_TIMES
 // Diagnostic build: wave cycles per section of k_wf_level, summed over all waves.
 __device__ unsigned long long g_section_cycles[8];
+// (summed per wave in scalar registers and added to the totals once, when the wave ends: an
+// atomic at every mark would make the next section wait for it)
 #define RT_SECTION(k)                                                              \
   do {                                                                             \
     const unsigned long long now_ = __builtin_readcyclecounter();                  \
-    if (threadIdx.x == 0) atomicAdd(&g_section_cycles[k], now_ - section_t_);      \
+    section_sum_[k] += now_ - section_t_;                                          \
     section_t_ = now_;                                                             \
   } while (0)
+#define RT_SECTION_FLUSH()                                                         \
+  do {                                                                             \
+    if (threadIdx.x == 0)                                                          \
+      for (int k_ = 0; k_ < 8; k_++)                                               \
+        if (section_sum_[k_]) atomicAdd(&g_section_cycles[k_], section_sum_[k_]);  \
+  } while (0)
 #else
+#define RT_SECTION_FLUSH() do { } while (0)
 #define RT_SECTION(k) do { } while (0)
 #endif
 
@@ -711,6 +720,7 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
   static_assert(COOP || !FAST, "the f32 search exists on the shared leaf tests only");
   RT_TRAV_STACK_COOP(st, S);
 #ifdef RT_SECTION_TIMES
+  unsigned long long section_sum_[8] = {};
   unsigned long long section_t_ = __builtin_readcyclecounter();
 #endif
   Counters cnt{};
@@ -848,6 +858,7 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
   // one dense byte per call tells the level's combine pass which nodes to touch at all
   if (spawn && (PRIMARY || active)) live[i] = has_children ? 1 : 0;
   RT_SECTION(5);
+  RT_SECTION_FLUSH();
   flush_counters<STATS>(cnt, counters);
 }
 

@@ -5,12 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import raytracer_amd as rt
 name, hs, vs = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else ("pawn", 1920, 1080)
+depth = int(sys.argv[4]) if len(sys.argv) > 4 else 5  # 1: the primary level alone
 w = rt.World.example(name, hs, vs).commit()
-w.render(); w.render()
+w.render(depth=depth); w.render(depth=depth)
 L = w.L
 out = (C.c_ulonglong * 8)()
 L.rt_debug_section_cycles(None, 1)
-w.render()
+w.render(depth=depth)
 torch.cuda.synchronize()
 L.rt_debug_section_cycles(out, 0)
 names = ["task load / ray generation", "closest-hit traversal", "prepare, pattern, lighting", "shadow traversal",
