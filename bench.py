@@ -155,7 +155,7 @@ def main():
                     help="GPU_MAX_HW_QUEUES for this process (HIP's default is 4: more frames in flight than "
                          "hardware queues share queues and serialise); 0 leaves the environment as it is; "
                          "-1 = 8 on one GPU, 12 per rank on several (the exchange has a stream of its own)")
-    ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh", "auto"],
+    ap.add_argument("--bvh", default="auto", choices=["sah", "lbvh", "auto"],
                     help="host binned-SAH build, device LBVH build, or by mesh size (device from 100k triangles on)")
     ap.add_argument("--sustain-s", type=float, default=1.0,
                     help="after the timed steps, the same loop again for at least this long (0 = skip)")

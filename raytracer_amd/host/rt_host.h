@@ -195,11 +195,11 @@ class DeviceScene {
   DeviceScene& operator=(const DeviceScene&) = delete;
   // Flattens `world` depth-first (the order the reference's sorts see) and commits it.
   // Returns false and sets error() on failure.
-  bool commit(const World& world, int device = -1, int bvh_builder = 0);
+  bool commit(const World& world, int device = -1, int bvh_builder = 2);
   // The same scene on several GPUs of the node (the first one assembles the frames): what the
   // reference does with `thread_count` threads (camera.rs:83-163).  render() then deals the
   // frame's tiles to all of them.
-  bool commit(const World& world, const std::vector<int>& devices, int bvh_builder = 0);
+  bool commit(const World& world, const std::vector<int>& devices, int bvh_builder = 2);
   bool multi() const { return multi_; }
   rt_scene* handle() const { return scene_; }
   const std::string& error() const { return error_; }
