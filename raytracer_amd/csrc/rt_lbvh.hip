@@ -5,6 +5,7 @@
 //   triangle boxes + mesh bounds  ->  63-bit Morton code of each centroid (21 bits per axis)
 //   ->  radix sort of (code, face)  ->  Karras' radix tree over the sorted codes (equal codes are
 //       told apart by their position)
+//   ->  the subtrees of at most 64 triangles built again by the surface-area heuristic
 //   ->  bottom-up refit  ->  collapse of subtrees with <= max_leaf triangles into leaves
 //   ->  binary nodes (both children's boxes on the mesh's 16-bit grid, rounded outward)
 //   ->  four-wide nodes, level by level from the root (so the top of the tree comes first,
@@ -171,6 +172,151 @@ __global__ void k_radix_tree(const unsigned long long* keys, int n, int* child_l
     parent_inner[gamma + 1] = i;
   }
   if (i == 0) parent_inner[0] = -1;
+}
+
+// ---- surface-area rebuild of the small subtrees ---------------------------------------------------
+// The radix tree splits where the Morton codes' bits change: spatial medians on a fixed cycle of
+// axes.  High up that is a fair tree; near the leaves, where a few dozen triangles are dealt out,
+// it is not.  Every maximal subtree of at most TREELET triangles is therefore built again by the
+// surface-area heuristic, top down, one wave per subtree with one triangle per lane: for each
+// axis the lanes rank their centroids, every lane prices the split behind its own rank
+// (area of the left box x its count + the same on the right), the cheapest of the three axes
+// wins, and the lanes trade places so that the two sides are contiguous again.  The subtree
+// keeps its root, its range of positions in the order array and the inner-node indices the
+// radix tree gave it: an inner left child is numbered by the last position of its range, an
+// inner right child by the first of its, which no two nodes of one subtree can share.
+constexpr int TREELET = 64;
+
+__global__ void k_find_treelets(const int* range_first, const int* range_last, const int* parent_inner,
+                                int n_inner, int* list, int* n_list) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_inner) return;
+  const int count = range_last[i] - range_first[i] + 1;
+  if (count > TREELET || count < 3) return;  // two triangles can be split one way only
+  const int p = parent_inner[i];
+  if (p >= 0 && range_last[p] - range_first[p] + 1 <= TREELET) return;  // part of a larger one
+  list[atomicAdd(n_list, 1)] = i;
+}
+
+__device__ inline float wave_min_f32(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ inline float lane_value(float v, int lane) {  // `lane` is the same for the whole wave
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
+}
+__device__ inline float send_to(float v, int dest_lane) {  // every lane receives what was sent to it
+  return __uint_as_float((unsigned)__builtin_amdgcn_ds_permute(dest_lane * 4, (int)__float_as_uint(v)));
+}
+
+__global__ void __launch_bounds__(64)
+k_rebuild_treelets(const int* list, int n_list, uint32_t* faces, const Box6* tri_boxes, int* child_l, int* child_r,
+                   int* range_first, int* range_last, int* parent_inner, int* parent_leaf) {
+  if ((int)blockIdx.x >= n_list) return;
+  const int root = list[blockIdx.x];
+  const int F = range_first[root], m = range_last[root] - F + 1;  // 3 <= m <= 64
+  const int lane = threadIdx.x;
+  __shared__ int todo_first[TREELET], todo_last[TREELET], todo_node[TREELET];
+  const float inf = __builtin_huge_valf();
+  float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+  unsigned face = 0;
+  if (lane < m) {
+    face = faces[F + lane];
+    const Box6 b = tri_boxes[face];
+    for (int a = 0; a < 3; a++) {
+      lo[a] = (float)b.lo[a];
+      hi[a] = (float)b.hi[a];
+    }
+  }
+  int sp = 0;
+  if (lane == 0) {
+    todo_first[0] = 0;
+    todo_last[0] = m - 1;
+    todo_node[0] = root;
+  }
+  sp = 1;
+  __syncthreads();
+  while (sp > 0) {  // the same for every lane
+    sp--;
+    const int f = __builtin_amdgcn_readfirstlane(todo_first[sp]), l = __builtin_amdgcn_readfirstlane(todo_last[sp]),
+              node = __builtin_amdgcn_readfirstlane(todo_node[sp]);
+    __syncthreads();
+    const int count = l - f + 1;
+    const bool in = lane >= f && lane <= l;
+    float best_cost = inf;
+    int best_left = count / 2;   // triangles that go left; without a finite price: half, as they stand
+    int best_rank = lane - f;
+    for (int axis = 0; axis < 3; axis++) {
+      float key = lo[axis] + hi[axis];
+      if (!(key == key)) key = 0.0f;  // the ranks must be a permutation whatever the input
+      int rank = 0;
+      for (int j = f; j <= l; j++) {
+        const float kj = lane_value(key, j);
+        rank += (kj < key || (kj == key && j < lane)) ? 1 : 0;
+      }
+      // this lane prices the split that puts the ranks 0..rank on the left
+      float ll[3] = {inf, inf, inf}, lh[3] = {-inf, -inf, -inf}, rl[3] = {inf, inf, inf}, rh[3] = {-inf, -inf, -inf};
+      for (int j = f; j <= l; j++) {
+        const bool left = __builtin_amdgcn_readlane(rank, j) <= rank;
+        for (int a = 0; a < 3; a++) {
+          const float bl = lane_value(lo[a], j), bh = lane_value(hi[a], j);
+          ll[a] = left ? fminf(ll[a], bl) : ll[a];
+          lh[a] = left ? fmaxf(lh[a], bh) : lh[a];
+          rl[a] = left ? rl[a] : fminf(rl[a], bl);
+          rh[a] = left ? rh[a] : fmaxf(rh[a], bh);
+        }
+      }
+      const float lx = lh[0] - ll[0], ly = lh[1] - ll[1], lz = lh[2] - ll[2];
+      const float rx = rh[0] - rl[0], ry = rh[1] - rl[1], rz = rh[2] - rl[2];
+      float cost = (lx * ly + ly * lz + lz * lx) * (float)(rank + 1) +
+                   (rx * ry + ry * rz + rz * rx) * (float)(count - rank - 1);
+      if (!in || rank >= count - 1 || !(cost == cost)) cost = inf;
+      const float cheapest = wave_min_f32(cost);
+      if (cheapest < best_cost) {  // the same for every lane
+        const int from = __ffsll((long long)__ballot(cost == cheapest)) - 1;
+        best_cost = cheapest;
+        best_left = __builtin_amdgcn_readlane(rank, from) + 1;
+        best_rank = rank;
+      }
+    }
+    // the lanes of this range trade places: rank order along the chosen axis
+    const int dest = in ? f + best_rank : lane;
+    for (int a = 0; a < 3; a++) {
+      lo[a] = send_to(lo[a], dest);
+      hi[a] = send_to(hi[a], dest);
+    }
+    face = (unsigned)__builtin_amdgcn_ds_permute(dest * 4, (int)face);
+    const int left_last = f + best_left - 1;
+    const bool left_leaf = best_left == 1, right_leaf = count - best_left == 1;
+    if (lane == 0) {
+      range_first[node] = F + f;
+      range_last[node] = F + l;
+      if (left_leaf) {
+        child_l[node] = (F + f) | LEAF_BIT;
+        parent_leaf[F + f] = node;
+      } else {
+        child_l[node] = F + left_last;
+        parent_inner[F + left_last] = node;
+        todo_first[sp] = f;
+        todo_last[sp] = left_last;
+        todo_node[sp] = F + left_last;
+      }
+      const int at = sp + (left_leaf ? 0 : 1);
+      if (right_leaf) {
+        child_r[node] = (F + l) | LEAF_BIT;
+        parent_leaf[F + l] = node;
+      } else {
+        child_r[node] = F + left_last + 1;
+        parent_inner[F + left_last + 1] = node;
+        todo_first[at] = left_last + 1;
+        todo_last[at] = l;
+        todo_node[at] = F + left_last + 1;
+      }
+    }
+    sp += (left_leaf ? 0 : 1) + (right_leaf ? 0 : 1);
+    __syncthreads();
+  }
+  if (lane < m) faces[F + lane] = face;
 }
 
 // Node boxes travel between workgroups: written and read with agent-scope atomics (a plain
@@ -587,7 +733,7 @@ int build_lbvh_resident(const double* p1, const double* p2, const double* p3, in
   LB_TRY(S.get(&node_cost, (size_t)n_inner));
   LB_TRY(S.get(&leafify, (size_t)n_inner));
   LB_TRY(hipMemset(leafify, 0, (size_t)n_inner * sizeof(int)));
-  float trav_cost = 1.5f;  // cost of a step down the binary tree, in triangle tests
+  float trav_cost = 2.0f;  // cost of a step down the binary tree, in triangle tests
   if (const char* e = getenv("RT_LBVH_TRAV")) trav_cost = (float)atof(e);
   LB_TRY(S.get(&child_l, (size_t)n_inner));
   LB_TRY(S.get(&child_r, (size_t)n_inner));
@@ -605,6 +751,23 @@ int build_lbvh_resident(const double* p1, const double* p2, const double* p3, in
   const dim3 igrid((unsigned)((n_inner + 255) / 256));
   hipLaunchKernelGGL(k_radix_tree, igrid, block, 0, 0, keys, n, child_l, child_r, range_first, range_last,
                      parent_inner, parent_leaf);
+  bool treelets = true;
+  if (const char* e = getenv("RT_LBVH_TREELETS")) treelets = atoi(e) != 0;
+  if (treelets) {
+    int *list, *n_list;
+    LB_TRY(S.get(&list, (size_t)n_inner));
+    LB_TRY(S.get(&n_list, 1));
+    LB_TRY(hipMemset(n_list, 0, sizeof(int)));
+    hipLaunchKernelGGL(k_find_treelets, igrid, block, 0, 0, range_first, range_last, parent_inner, n_inner, list, n_list);
+    LB_TRY(hipGetLastError());
+    int count = 0;
+    LB_TRY(hipMemcpy(&count, n_list, sizeof(int), hipMemcpyDeviceToHost));
+    if (count > 0) {
+      hipLaunchKernelGGL(k_rebuild_treelets, dim3((unsigned)count), dim3(64), 0, 0, list, count, d_order, boxes, child_l,
+                         child_r, range_first, range_last, parent_inner, parent_leaf);
+      LB_TRY(hipGetLastError());
+    }
+  }
   hipLaunchKernelGGL(k_refit, grid, block, 0, 0, d_order, boxes, n, child_l, child_r, parent_inner, parent_leaf,
                      arrivals, node_boxes, node_depth, range_first, range_last, max_leaf, trav_cost, node_cost, leafify);
   hipLaunchKernelGGL(k_mark_live, igrid, block, 0, 0, range_first, range_last, parent_inner, leafify, n_inner, max_leaf,

@@ -171,6 +171,21 @@ def test_device_built_bvh(rt, O, name, size, ntris):
     assert sb.rays_shadow == cnt["shadow"]
 
 
+def test_device_built_bvh_with_and_without_rebuilt_subtrees(rt, monkeypatch):
+    """The device builder rebuilds the radix tree's subtrees of up to 64 triangles by the
+    surface-area heuristic (RT_LBVH_TREELETS=0 keeps them): another tree, fewer triangle tests,
+    the same frame."""
+    frames, tests = [], []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RT_LBVH_TREELETS", flag)
+        w = rt.World.example("pawn", 320, 180).commit(bvh_builder=1)
+        u8, f64, st = w.render(want_f64=True, want_stats=True)
+        frames.append(f64)
+        tests.append(st.tri_tests + 4 * st.nodes_visited)
+    assert np.array_equal(frames[0], frames[1])
+    assert tests[0] < tests[1]
+
+
 def test_bvh_builder_by_mesh_size(rt, O):
     """bvh_builder=2: meshes of 100 000 triangles and more are built on the device, smaller ones
     on the host; the frame is the host build's."""
@@ -469,7 +484,7 @@ def test_random_scenes(rt, O, seed):
     assert np.abs(f64 - of64).max() <= 1e-11
 
 
-@pytest.mark.parametrize("n_tris", [1, 2, 3, 13, 16, 17, 400])
+@pytest.mark.parametrize("n_tris", [1, 2, 3, 13, 16, 17, 63, 64, 65, 129, 400])
 @pytest.mark.parametrize("bvh_builder", [0, 1])
 def test_mesh_sizes_around_the_leaf_limits(rt, O, n_tris, bvh_builder):
     """Meshes of one triangle, of exactly one leaf, of one leaf plus one, ... with both BVH
