@@ -733,7 +733,9 @@ int build_lbvh_resident(const double* p1, const double* p2, const double* p3, in
   LB_TRY(S.get(&node_cost, (size_t)n_inner));
   LB_TRY(S.get(&leafify, (size_t)n_inner));
   LB_TRY(hipMemset(leafify, 0, (size_t)n_inner * sizeof(int)));
-  float trav_cost = 2.0f;  // cost of a step down the binary tree, in triangle tests
+  // cost of a step down the binary tree, in triangle tests (measured: 2 renders the pawn and the
+  // tea set fastest; the 1 M-triangle soup wants smaller leaves: 1.5 there is 3 % faster than 2)
+  float trav_cost = n >= 100000 ? 1.5f : 2.0f;
   if (const char* e = getenv("RT_LBVH_TRAV")) trav_cost = (float)atof(e);
   LB_TRY(S.get(&child_l, (size_t)n_inner));
   LB_TRY(S.get(&child_r, (size_t)n_inner));
