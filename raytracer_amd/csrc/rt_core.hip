@@ -1278,6 +1278,18 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
     M.n_nodes = mn.count;
     node_total += mn.count;
     tri_total += h.ntris;
+    {
+      const double inf = std::numeric_limits<double>::infinity();
+      double wlo[3], whi[3];
+      const bool known = world_bounds_of_box(s, M.group, M.lo, M.hi, wlo, whi);
+      for (int a = 0; a < 3; a++) {
+        // padded like the boxes of the closed-form shapes: 1e-6 of the size, far above the
+        // rounding of the f64 slab test and of the corner transforms
+        const double pad = known ? 1e-6 * (whi[a] - wlo[a]) + 1e-9 * std::fmax(std::fabs(wlo[a]), std::fabs(whi[a])) + 1e-300 : 0.0;
+        M.wlo[a] = known ? wlo[a] - pad : -inf;
+        M.whi[a] = known ? whi[a] + pad : inf;
+      }
+    }
   }
   // the node table: every mesh's nodes back to back (indices were offset when they were made)
   DNode4* d_nodes = nullptr;

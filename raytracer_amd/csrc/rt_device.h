@@ -381,6 +381,22 @@ __device__ __forceinline__ bool cube_cull_unsafe(const DScene& S, const DPrim& P
   d = xf_vector(P.inv, d);
   return fabs(d.x) < EPS || fabs(d.y) < EPS || fabs(d.z) < EPS;
 }
+#ifndef RT_WORLD_BOUNDS
+#define RT_WORLD_BOUNDS 1
+#endif
+// the same test against a mesh's world-space bounds (DMesh::wlo / whi; infinite ones always pass)
+__device__ __forceinline__ bool bounds_may_hit(const double* lo, const double* hi, const BoxRay& r, double tlo,
+                                               double thi) {
+  double tin = tlo, tout = thi;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    double t0 = (lo[a] - r.o[a]) * r.inv[a], t1 = (hi[a] - r.o[a]) * r.inv[a];
+    tin = fmax(tin, fmin(t0, t1));
+    tout = fmin(tout, fmax(t0, t1));
+  }
+  return !(tin > tout + 1e-9 * (fabs(tin) + fabs(tout)));
+}
+
 // true when primitive p can be skipped for intersections inside (tlo, thi)
 __device__ __forceinline__ bool prim_culled(const DScene& S, int p, const Ray& ray, const BoxRay& br, double tlo,
                                             double thi) {
@@ -1015,14 +1031,29 @@ __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q
 // leaves of 1-6 triangles costs one 64-wide test instead of three 10-wide pair tests.  The
 // owner of a leaf takes the results (t, u, v) of its triangles from the workers' registers;
 // they are the same arithmetic on the same operands as the per-lane path computes.
+// `wr`: the world-space ray prepared for box tests (make_box_ray; read for enabled lanes only).
 template <int MODE, bool STATS, bool FAST>
-__device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Query& q, bool enabled,
-                                            Counters& cnt, TravStack& st) {
+__device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, const BoxRay& wr, Query& q,
+                                            bool enabled, Counters& cnt, TravStack& st) {
   const int lane = threadIdx.x & 63;
   bool satisfied = false;  // Q_ANY: this lane has its answer
   if (__ballot(enabled) == 0ull) return false;  // no lane of the wave has a query (wave-uniform)
+  // A query whose interval misses a mesh's bounds in world space has nothing to find in it, and
+  // a wave without any other query skips the mesh before a ray is taken into its space.  The
+  // tests are made up front, on the interval the query starts with, and kept as one bit per
+  // mesh (the first 64; later ones are always walked): the world-space ray is then done with.
+  unsigned long long may = ~0ull;
+  if (RT_WORLD_BOUNDS && enabled) {
+    const double below = (MODE == Q_PRED) ? (q.found ? q.best.t - q.tau : -RT_INF) : 0.0;
+    const double above = (MODE == Q_CLOSEST) ? q.hi + q.tau : q.hi;
+    may = 0ull;
+    for (int m = 0; m < S.n_meshes && m < 64; m++)
+      if (bounds_may_hit(S.meshes[m].wlo, S.meshes[m].whi, wr, below, above)) may |= 1ull << m;
+  }
   for (int m = 0; m < S.n_meshes; m++) {
     const DMesh& M = S.meshes[m];
+    const bool wanted = enabled && !satisfied && (m >= 64 || ((may >> m) & 1ull));
+    if (__ballot(wanted) == 0ull) continue;  // wave-uniform
     Ray lr = ray;
     CullRay c;
     c.miss = true;
@@ -1030,7 +1061,7 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, Que
     for (int a = 0; a < 3; a++) {
       c.a[a] = 0.f; c.nf[a].x = 0.f; c.nf[a].y = 0.f; c.sh[a] = 0;
     }
-    const bool walking0 = enabled && !satisfied;
+    const bool walking0 = wanted;
     if (walking0) {
       lr = ray_to_group(S, M.group, ray);
       if (STATS) cnt.inst_entries++;
@@ -1321,8 +1352,9 @@ __device__ inline bool trace_closest_coop(const DScene& S, const Ray& ray, bool 
   q.v = 0.0;
   q.best = Key{0.0, 0u, 0};
   int prim = -1;
+  BoxRay br = {};
   if (enabled) {
-    const BoxRay br = make_box_ray(ray);
+    br = make_box_ray(ray);
     for (int p = 0; p < S.n_prims; p++) {
       if (prim_culled(S, p, ray, br, 0.0, q.hi)) continue;
       const DPrim& P = S.prims[p];
@@ -1341,7 +1373,7 @@ __device__ inline bool trace_closest_coop(const DScene& S, const Ray& ray, bool 
       }
     }
   }
-  traverse_meshes_coop<Q_CLOSEST, STATS, FAST>(S, ray, q, enabled, cnt, st);
+  traverse_meshes_coop<Q_CLOSEST, STATS, FAST>(S, ray, br, q, enabled, cnt, st);
   h.t = q.hi;
   h.order = q.hi_order;
   h.u = q.u;
@@ -1356,8 +1388,9 @@ template <bool STATS, bool FAST>
 __device__ inline bool trace_any_coop(const DScene& S, const Ray& ray, double distance, bool enabled,
                                       Counters& cnt, TravStack& st) {
   bool found = false;
+  BoxRay br = {};
   if (enabled) {
-    const BoxRay br = make_box_ray(ray);
+    br = make_box_ray(ray);
     for (int p = 0; p < S.n_prims && !found; p++) {
       if (prim_culled(S, p, ray, br, 0.0, distance)) continue;
       const DPrim& P = S.prims[p];
@@ -1379,7 +1412,7 @@ __device__ inline bool trace_any_coop(const DScene& S, const Ray& ray, double di
   q.tri = -1;
   q.u = q.v = 0.0;
   q.best = Key{0.0, 0u, 0};
-  bool mesh_hit = traverse_meshes_coop<Q_ANY, STATS, FAST>(S, ray, q, enabled && !found, cnt, st);
+  bool mesh_hit = traverse_meshes_coop<Q_ANY, STATS, FAST>(S, ray, br, q, enabled && !found, cnt, st);
   return found || mesh_hit;
 }
 
@@ -1397,7 +1430,9 @@ __device__ inline bool tri_predecessor_coop(const DScene& S, const Ray& ray, con
   q.tri = own_tri;
   q.u = q.v = 0.0;
   q.best = Key{0.0, 0u, 0};
-  traverse_meshes_coop<Q_PRED, STATS, FAST>(S, ray, q, enabled, cnt, st);
+  BoxRay br = {};
+  if (enabled) br = make_box_ray(ray);
+  traverse_meshes_coop<Q_PRED, STATS, FAST>(S, ray, br, q, enabled, cnt, st);
   if (enabled && q.found) {
     best = q.best;
     best_mesh = q.mesh;

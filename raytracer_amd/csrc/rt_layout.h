@@ -32,6 +32,9 @@ struct alignas(16) DMesh {
   int32_t ntris;
   int32_t n_nodes;      // nodes of this mesh; the first ones are the top of the tree, breadth first
   int32_t pad;
+  // the same bounds in world space (through the mesh's groups), padded; infinite when unknown:
+  // a query whose ray misses them need not be taken into the mesh's space at all
+  double wlo[3], whi[3];
 };
 // One triangle as the intersection test reads it: p1, e1 = p2-p1, e2 = p3-p1
 // (triangle.rs:49-50).  80 bytes.
