@@ -739,9 +739,7 @@ __device__ __forceinline__ bool accept_hit_select(bool valid, double t, double u
     q.hi_order = take ? ord : q.hi_order;
     q.mesh = take ? m : q.mesh;
     q.tri = take ? rec : q.tri;
-    q.u = take ? u : q.u;
-    q.v = take ? v : q.v;
-    q.found = q.found | take;
+    q.found = q.found | take;  // (q.u, q.v: filled in by trace_closest_coop when the walk is over)
     return false;
   } else if (MODE == Q_ANY) {
     return valid & (t > 0.0) & (t < q.hi);
@@ -1202,8 +1200,10 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, con
             hit_any |= accept_fast<MODE, STATS>(S, lr, mine != 0ull, (int)(orig >> 30), t, et,
                                                 order_base + (orig & 0x3fffffffu), m, tri_base + rec, q, cnt);
           } else {
-            const double t = __shfl(wt, src, 64), u = __shfl(wu, src, 64), v = __shfl(wv, src, 64);
-            hit_any |= accept_hit_select<MODE>(mine != 0ull, t, u, v, order_base + orig, m, tri_base + rec, q);
+            // (u and v stay with the worker: the closest-hit query evaluates its final triangle
+            // once more when the walk is over, see trace_closest_coop)
+            const double t = __shfl(wt, src, 64);
+            hit_any |= accept_hit_select<MODE>(mine != 0ull, t, 0.0, 0.0, order_base + orig, m, tri_base + rec, q);
           }
           mine &= mine - 1ull;  // 0 stays 0
         }
@@ -1374,6 +1374,13 @@ __device__ inline bool trace_closest_coop(const DScene& S, const Ray& ray, bool 
     }
   }
   traverse_meshes_coop<Q_CLOSEST, STATS, FAST>(S, ray, br, q, enabled, cnt, st);
+  if (!FAST && enabled && q.mesh >= 0) {
+    // u, v of the triangle that won: the same test on the same operands as the worker ran,
+    // hence the same bits (and the same t)
+    const Ray lr = ray_to_group(S, S.meshes[q.mesh].group, ray);
+    double t;
+    moller_trumbore(S.tris[q.tri], lr, t, q.u, q.v);
+  }
   h.t = q.hi;
   h.order = q.hi_order;
   h.u = q.u;
