@@ -8,3 +8,8 @@ run RT_MAX_LEAF=1
 run RT_MAX_LEAF=4
 run RT_MAX_LEAF=15
 run RT_SAH_TRAV=1
+run RT_SAH_BOTTOMUP=0
+run RT_SAH_SWEEP=100000000
+run RT_LBVH_TREELETS=0
+run RT_LBVH_TRAV=1
+run RT_SORT_RAYS=1
