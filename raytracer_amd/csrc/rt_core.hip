@@ -810,32 +810,45 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
     pr.mat_index = 0;
     C3 surface = {0.0, 0.0, 0.0};
     C3 pc = {0.0, 0.0, 0.0};
+    // Everything of a call that does not hang on the shadow queries is done before them: the
+    // child rays (they depend on the optics alone, world.rs:78-114) are queued, and each light's
+    // contribution is evaluated both ways (lit and shadowed), so that a query leaves one
+    // select and three additions behind and nothing of the hit has to live through its walk.
+    V3 eyev = {0.0, 0.0, 0.0}, normal = {0.0, 0.0, 0.0}, over = {0.0, 0.0, 0.0};
     if (hit) {
       if (STATS) cnt.shade_calls++;
       pr = prepare_hit(S, ray, h);
       pc = hit_pattern_color(S, S.mats[pr.mat_index], pr);
+      eyev = vneg(ray.d);
+      normal = pr.normal;
+      over = pr.over;
+      ShadeOut so;
+      finish_optics(S.mats[pr.mat_index], ray, pr, n1, n2, so);
+      has_children = emit_result<STATS>(so, surface, nd, i, next, next_count, next_cap, spawn, cnt, grid, next_keys, hist);
     }
     for (int li = 0; li < S.n_lights; li++) {
       const DLight& L = S.lights[li];
-      Ray sr = ray;
+      Ray sr = {over, v3(0.0, 0.0, 1.0)};
       double distance = 0.0;
+      C3 lit = {0.0, 0.0, 0.0}, dark = {0.0, 0.0, 0.0};
       if (hit) {
-        shadow_ray(L, pr.over, sr, distance);
+        shadow_ray(L, over, sr, distance);
         if (STATS) cnt.rays_shadow++;
+        light_terms(S.mats[pr.mat_index], L, pc, sr.d, normal, eyev, lit, dark);
       }
       RT_SECTION(2);
       const bool shadow = trace_any_coop<STATS, FAST>(S, sr, distance, hit, cnt, st);
       RT_SECTION(3);
-      if (hit) add_light(S.mats[pr.mat_index], L, pc, sr.d, pr.normal, vneg(ray.d), shadow, surface);
+      if (hit) {
+        surface.r += shadow ? dark.r : lit.r;
+        surface.g += shadow ? dark.g : lit.g;
+        surface.b += shadow ? dark.b : lit.b;
+      }
     }
     if (hit) {
-      const DMaterial& M = S.mats[pr.mat_index];
-      ShadeOut so;
-      // the same expression prepare_hit evaluated (intersect.rs:184): computed again here so that
-      // the point need not stay in registers through the shadow queries
-      pr.under = vsub(ray_at(ray, h.t), vmul(pr.normal, EPS));
-      finish_optics(M, ray, pr, n1, n2, so);
-      has_children = emit_result<STATS>(so, surface, nd, i, next, next_count, next_cap, spawn, cnt, grid, next_keys, hist);
+      nd.surface[0] = surface.r;
+      nd.surface[1] = surface.g;
+      nd.surface[2] = surface.b;
     }
   } else {
     if (active) {

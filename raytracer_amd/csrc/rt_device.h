@@ -1714,6 +1714,29 @@ __device__ inline double pow_specular(double x, double y) {
   return __hiloint2double(__double2hiint(e) + ((n + 1000) << 20), __double2loint(e)) * 9.33263618503218878990e-302;
 }
 
+// The two values add_light can add for one light, both evaluated before the shadow query: the
+// same expressions, so whichever the query selects is the same bits (a shadowed light adds
+// ambient + 0 + 0).
+__device__ inline void light_terms(const DMaterial& M, const DLight& L, C3 pc, V3 lightv, V3 normal, V3 eyev,
+                                   C3& lit, C3& dark) {
+  C3 eff = {pc.r * L.intensity[0], pc.g * L.intensity[1], pc.b * L.intensity[2]};
+  C3 ambient = {eff.r * M.ambient, eff.g * M.ambient, eff.b * M.ambient};
+  double ldn = vdot(lightv, normal);
+  C3 diffuse = {0.0, 0.0, 0.0}, specular = {0.0, 0.0, 0.0};
+  if (!(ldn < 0.0)) {
+    diffuse = {eff.r * M.diffuse * ldn, eff.g * M.diffuse * ldn, eff.b * M.diffuse * ldn};
+    V3 rv = vreflect(vneg(lightv), normal);
+    double rde = vdot(rv, eyev);
+    if (!(rde <= 0.0)) {
+      double factor = pow_specular(rde, M.shininess);
+      specular = {L.intensity[0] * M.specular * factor, L.intensity[1] * M.specular * factor,
+                  L.intensity[2] * M.specular * factor};
+    }
+  }
+  lit = {ambient.r + diffuse.r + specular.r, ambient.g + diffuse.g + specular.g, ambient.b + diffuse.b + specular.b};
+  dark = {ambient.r + 0.0 + 0.0, ambient.g + 0.0 + 0.0, ambient.b + 0.0 + 0.0};
+}
+
 __device__ inline void add_light(const DMaterial& M, const DLight& L, C3 pc, V3 lightv, V3 normal,
                                  V3 eyev, bool shadow, C3& surface) {
   C3 eff = {pc.r * L.intensity[0], pc.g * L.intensity[1], pc.b * L.intensity[2]};

@@ -14,8 +14,9 @@ L.rt_debug_section_cycles(None, 1)
 w.render(depth=depth)
 torch.cuda.synchronize()
 L.rt_debug_section_cycles(out, 0)
-names = ["task load / ray generation", "closest-hit traversal", "prepare, pattern, lighting", "shadow traversal",
-         "predecessor traversal", "containers, optics, emit, node write"]
+names = ["task load / ray generation", "closest-hit traversal",
+         "containers, hit preparation, pattern, optics, child rays, light terms", "shadow traversal",
+         "predecessor traversal", "surface sum, node write"]
 tot = sum(out[:6])
 for n, v in zip(names, out):
     print(f"{n:40s} {100.0 * v / tot:5.1f} %  {v / 1e6:10.1f} Mcycles")
