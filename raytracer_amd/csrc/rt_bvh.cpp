@@ -67,7 +67,6 @@ struct Builder {
   // greedy stop and the pawn as fast; sweeping every range is slower on the pawn)
   bool bottom_up = true;
   int sweep_below = 64;
-  std::vector<uint32_t> scratch;
   std::vector<double> suffix;
 
   // exact search over the sorted order of one axis; leaves idx[first..first+count) sorted by it
