@@ -171,6 +171,7 @@ def main():
 
     import torch
     import raytracer_amd as rt
+    from raytracer_amd import parallel
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -228,12 +229,12 @@ def main():
         """The one exchange step: shards -> rank 0 (RCCL gather), de-tile kernel there."""
         stream = torch.cuda.current_stream().cuda_stream
         if rehearsal:
-            h = [torch.zeros(tiles[slot].numel(), dtype=torch.uint8) for _ in range(n)] if rank == 0 else None
-            dist.gather(tiles[slot].cpu(), h, dst=0)
+            h = parallel.gather_tiles(tiles[slot].cpu(), rank, n, dist)
             if rank == 0:
                 all_tiles[slot].copy_(torch.stack(h))
         else:
-            dist.gather(tiles[slot], list(all_tiles[slot].unbind(0)) if rank == 0 else None, dst=0)
+            parallel.gather_tiles(tiles[slot], rank, n, dist,
+                                  out=list(all_tiles[slot].unbind(0)) if rank == 0 else None)
         if rank == 0:
             rt.detile_u8(all_tiles[slot].data_ptr(), n, per, hs, vs, images[slot].data_ptr(), stream)
 

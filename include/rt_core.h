@@ -206,6 +206,10 @@ int64_t rt_shard_tiles(int hsize, int vsize, int tile_first, int tile_step);
  * writes the row-major hsize*vsize*3 image to d_image.  Asynchronous on hip_stream. */
 int rt_detile_u8(const uint8_t* d_tiles, int nshards, int64_t tiles_per_shard, int hsize,
                  int vsize, uint8_t* d_image, void* hip_stream);
+/* The same for shards of f64 colours (the Canvas of draw/canvas.rs:6-27 holds f64 colours):
+ * buffers of tiles_per_shard*RT_TILE*RT_TILE*3 doubles. */
+int rt_detile_f64(const double* d_tiles, int nshards, int64_t tiles_per_shard, int hsize,
+                  int vsize, double* d_image, void* hip_stream);
 
 /* ---- several GPUs of one node ------------------------------------------------------------ */
 /* Replaces what scene::camera::render does with threads: the shared World/Camera
@@ -219,12 +223,25 @@ int rt_detile_u8(const uint8_t* d_tiles, int nshards, int64_t tiles_per_shard, i
  * device_ids[0]); at least one must be given.  The image is the one rt_render produces, byte for
  * byte, for every ndev; ndev = 1 runs the same steps (its shard goes through RCCL to itself).
  * stats (may be NULL): counters summed over the GPUs, kernel_ms the slowest GPU's.
- * One host thread per scene; the call returns when the image is complete.  A scene whose
- * rt_scene_commit_multi failed can only be destroyed (rt_render_multi refuses it).  Both calls
- * leave the caller's current HIP device as they found it. */
+ * One host thread per scene calls in; the call returns when the image is complete.  (Inside,
+ * the replicas are committed, and a frame not rendered before is planned, by one short-lived
+ * host thread per GPU, so that the GPUs work side by side; trees the host builds are built once
+ * and uploaded to every GPU.)  After rt_scene_commit_multi the single-GPU entry points
+ * (rt_render, rt_render_device, rt_render_device_noalloc) keep working on the scene: they use
+ * device_ids[0] alone.  A scene whose rt_scene_commit_multi failed can only be destroyed
+ * (rt_render_multi refuses it).  All calls leave the caller's current HIP device as they found it.
+ * Verified on one GPU only (ndev = 1, where the shard is sent to itself); ndev > 1 has not run
+ * on hardware. */
 int rt_scene_commit_multi(rt_scene*, const int* device_ids, int ndev, int bvh_builder);
 int rt_render_multi(rt_scene*, const rt_camera*, int depth, int mode, int pipeline,
                     uint8_t* out_rgb_u8, uint8_t* d_rgb_u8, rt_stats* stats);
+/* The same frame with the f64 colours the reference's Canvas holds (draw/canvas.rs:6-27) as
+ * well as, or instead of, the quantised ones: out_rgb_f64 (host) and/or d_rgb_f64 (device memory
+ * on device_ids[0]), hsize*vsize*3 doubles, row-major; any of the four outputs may be NULL, not
+ * all.  The f64 shards travel in the same grouped exchange (ncclDouble). */
+int rt_render_multi_f64(rt_scene*, const rt_camera*, int depth, int mode, int pipeline,
+                        double* out_rgb_f64, double* d_rgb_f64, uint8_t* out_rgb_u8,
+                        uint8_t* d_rgb_u8, rt_stats* stats);
 /* GPUs a committed scene lives on (1 after rt_scene_commit), 0 if not committed */
 int rt_scene_device_count(const rt_scene*);
 

@@ -61,7 +61,7 @@ int rth_get_camera(rth_world*, rt_camera* out);
 
 /* flatten + rt_scene_commit; the world must not change afterwards */
 int rth_commit(rth_world*, int device, int bvh_builder);
-/* the same on several GPUs (rt_scene_commit_multi); rth_render then uses all of them (u8 output only) */
+/* the same on several GPUs (rt_scene_commit_multi); rth_render then uses all of them (rt_render_multi_f64) */
 int rth_commit_multi(rth_world*, const int* device_ids, int ndev, int bvh_builder);
 rt_scene* rth_scene(rth_world*);
 /* scene::camera::render, camera.rs:83 (host buffers; see rt_render) */

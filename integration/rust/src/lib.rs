@@ -171,6 +171,15 @@ extern "C" {
         d_image: *mut u8,
         hip_stream: *mut c_void,
     ) -> c_int;
+    pub fn rt_detile_f64(
+        d_tiles: *const f64,
+        nshards: c_int,
+        tiles_per_shard: i64,
+        hsize: c_int,
+        vsize: c_int,
+        d_image: *mut f64,
+        hip_stream: *mut c_void,
+    ) -> c_int;
     pub fn rt_scene_commit_multi(s: *mut c_void, device_ids: *const c_int, ndev: c_int, bvh_builder: c_int) -> c_int;
     pub fn rt_render_multi(
         s: *mut c_void,
@@ -178,6 +187,18 @@ extern "C" {
         depth: c_int,
         mode: c_int,
         pipeline: c_int,
+        out_rgb_u8: *mut u8,
+        d_rgb_u8: *mut u8,
+        stats: *mut RtStats,
+    ) -> c_int;
+    pub fn rt_render_multi_f64(
+        s: *mut c_void,
+        cam: *const RtCamera,
+        depth: c_int,
+        mode: c_int,
+        pipeline: c_int,
+        out_rgb_f64: *mut f64,
+        d_rgb_f64: *mut f64,
         out_rgb_u8: *mut u8,
         d_rgb_u8: *mut u8,
         stats: *mut RtStats,
@@ -332,6 +353,25 @@ impl Scene {
             panic!("rt_trace_rays: {}", last_error());
         }
         out
+    }
+    /// One frame as the reference's Canvas holds it (draw/canvas.rs:6-27): `hsize*vsize*3` f64
+    /// colour components, row-major, unclamped.
+    pub fn render_f64(&self, cam: &RtCamera, depth: i32) -> Vec<f64> {
+        let mut rgb = vec![0f64; cam.hsize as usize * cam.vsize as usize * 3];
+        let rc = unsafe {
+            if self.multi {
+                rt_render_multi_f64(self.raw, cam, depth, RT_MODE_F64_PARITY, RT_PIPELINE_WAVEFRONT, rgb.as_mut_ptr(),
+                                    std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut(),
+                                    std::ptr::null_mut())
+            } else {
+                rt_render(self.raw, cam, depth, RT_MODE_F64_PARITY, RT_PIPELINE_WAVEFRONT, rgb.as_mut_ptr(),
+                          std::ptr::null_mut(), std::ptr::null_mut())
+            }
+        };
+        if rc != 0 {
+            panic!("render: {}", last_error());
+        }
+        rgb
     }
     /// One frame, quantised as Color::clamp does (draw/color.rs:148-155): `hsize*vsize*3` bytes.
     pub fn render_rgb8(&self, cam: &RtCamera, depth: i32) -> Vec<u8> {

@@ -172,6 +172,9 @@ def lib():
     L.rth_commit.argtypes = [vp, C.c_int, C.c_int]
     L.rth_commit_multi.argtypes = [vp, C.POINTER(C.c_int), C.c_int, C.c_int]
     L.rt_render_multi.argtypes = [vp, C.POINTER(CameraABI), C.c_int, C.c_int, C.c_int, u8p, vp, C.POINTER(Stats)]
+    L.rt_render_multi_f64.argtypes = [vp, C.POINTER(CameraABI), C.c_int, C.c_int, C.c_int, dp, vp, u8p, vp,
+                                      C.POINTER(Stats)]
+    L.rt_detile_f64.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp]
     L.rt_scene_device_count.argtypes = [vp]
     L.rth_scene.argtypes = [vp]
     L.rth_scene.restype = vp
@@ -299,6 +302,25 @@ class World:
             self._err("commit_multi")
         self.committed = True
         return self
+
+    def render_multi_f64(self, d_f64=None, d_u8=None, want_host_f64=True, want_host_u8=True, depth=5,
+                         mode=MODE_F64_PARITY, pipeline=None, want_stats=False, cam=None):
+        """rt_render_multi_f64: returns (f64 HxWx3 or None, u8 HxWx3 or None, Stats or None); d_f64 /
+        d_u8 = device pointers on the first GPU for the stitched images."""
+        pipeline = DEFAULT_PIPELINE if pipeline is None else pipeline
+        cam = cam or self.camera_abi()
+        n = cam.hsize * cam.vsize * 3
+        f64 = np.zeros(n) if want_host_f64 else None
+        u8 = np.zeros(n, dtype=np.uint8) if want_host_u8 else None
+        st = Stats() if want_stats else None
+        rc = self.L.rt_render_multi_f64(self.scene, C.byref(cam), depth, mode, pipeline,
+                                        _dp(f64) if want_host_f64 else None, C.c_void_p(d_f64 or 0),
+                                        u8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_host_u8 else None,
+                                        C.c_void_p(d_u8 or 0), C.byref(st) if want_stats else None)
+        if rc != 0:
+            raise RtError(f"rt_render_multi_f64: {self.L.rt_last_error().decode()}")
+        shape = (cam.vsize, cam.hsize, 3)
+        return (f64.reshape(shape) if want_host_f64 else None), (u8.reshape(shape) if want_host_u8 else None), st
 
     def render_multi(self, d_u8=None, want_host=True, depth=5, mode=MODE_F64_PARITY, pipeline=None,
                      want_stats=False, cam=None):

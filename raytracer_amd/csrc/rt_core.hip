@@ -12,7 +12,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_core.h"
@@ -42,6 +44,38 @@ struct MeshH {
   std::vector<double> p1, p2, p3, n1, n2, n3;
   std::vector<uint8_t> smooth;
   bool has_normals;
+};
+
+// Everything that fixes a frame's ray-queue lengths.  Plans and pipeline choices are found by a
+// hash of these fields and then compared field by field, so two frames that happen to share a
+// hash never share a plan.
+struct FrameId {
+  DCamera dc;
+  int32_t tile_first, tile_step, depth, fast, compact;
+};
+static FrameId frame_id(const DCamera& dc, int tile_first, int tile_step, int depth, bool fast, bool compact) {
+  FrameId f;
+  std::memset(&f, 0, sizeof f);  // padding too: the identities are compared as bytes
+  f.dc = dc;
+  f.tile_first = tile_first;
+  f.tile_step = tile_step;
+  f.depth = depth;
+  f.fast = fast ? 1 : 0;
+  f.compact = compact ? 1 : 0;
+  return f;
+}
+static bool same_frame(const FrameId& a, const FrameId& b) { return std::memcmp(&a, &b, sizeof a) == 0; }
+
+// What the host builder made of one mesh: the four-wide nodes (child indices relative to the
+// mesh's first node) and the triangle records in leaf order.  rt_scene_commit_multi keeps these
+// while it commits the replicas, so the tree is built once, not once per GPU.
+struct HostBuilt {
+  std::vector<DNode4> nodes;
+  std::vector<DTri> tris;
+  std::vector<DTriF> trisf;
+  std::vector<DTriN> trin;
+  double lo[3], hi[3], cell[3], scale;
+  int stack_need;
 };
 
 struct Multi;
@@ -88,6 +122,7 @@ struct rt_scene {
     // a frame issued on an estimate whose counters are on their way to wf_counts_host
     bool estimate_pending = false;
     uint64_t estimate_key = 0;
+    FrameId estimate_id{};
     int estimate_depth = 0;
     long long estimate_n0 = 0;
     bool estimate_fast = false;
@@ -115,12 +150,18 @@ struct rt_scene {
   // Wavefront kernels share the triangle tests of a wave's leaves between all its lanes
   // (traverse_meshes_coop): pawn 1080p 7.0 -> 5.5 ms, tea set 1.08 -> 1.01 ms.
   // RT_SHARE_LEAVES=0 selects the per-lane leaf tests instead.
-  std::vector<std::pair<uint64_t, int>> auto_choice;  // frame key -> pipeline picked by RT_PIPELINE_AUTO
+  struct AutoChoice {
+    uint64_t key;
+    FrameId id;
+    int pipeline;
+  };
+  std::vector<AutoChoice> auto_choice;  // frame -> pipeline picked by RT_PIPELINE_AUTO
   bool share_leaves = true;
   // Queue lengths of frames rendered with host read-backs: the same frame (camera, shard,
   // depth, mode) is then issued again without any synchronisation.
   struct WfPlan {
     uint64_t key = 0;
+    FrameId id{};
     int levels = 0;
     int depth = 0;
     bool fast = false;
@@ -138,10 +179,10 @@ struct rt_scene {
   int sort_min_level = 2;
   std::vector<hipStream_t> split_streams;
   std::vector<hipStream_t> recent_streams;  // caller streams of the last four wavefront frames
-  // A shard of one tile still goes to a compact tile buffer, not to the row-major image (set on
-  // the replicas of a multi-GPU scene, whose one shard of one is stitched like any other).
-  bool compact_always = false;
   struct Multi* multi = nullptr;  // rt_scene_commit_multi: replicas on other GPUs, RCCL, buffers
+  // per mesh, during rt_scene_commit_multi only: the host builder's result, shared with the replicas
+  std::vector<std::shared_ptr<HostBuilt>> host_built;
+  bool keep_host_built = false;
   std::vector<hipEvent_t> split_joined;
   hipEvent_t split_fork = nullptr;
 };
@@ -389,8 +430,9 @@ __global__ void __launch_bounds__(64) k_trace_rays(DScene S, long long n, const 
 }
 
 // stitch of tile shards into the row-major image (canvas.rs:47-64 for tiles)
-__global__ void k_detile_u8(const uint8_t* tiles, int nshards, long long tiles_per_shard, int hsize,
-                            int vsize, int tiles_x, uint8_t* image) {
+template <typename T>
+__global__ void k_detile(const T* tiles, int nshards, long long tiles_per_shard, int hsize,
+                         int vsize, int tiles_x, T* image) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // pixel index
   long long npx = (long long)hsize * vsize;
   if (i >= npx) return;
@@ -1212,80 +1254,95 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
       }
       M.scale = mn.dev.scale;
     } else {
-      rtb::BuildResult br;
-      rtb::build_sah(h.p1.data(), h.p2.data(), h.p3.data(), h.ntris, max_leaf, br);
-      // the kernels walk four-wide nodes; a step leaves up to three children on the stack
-      const int stack_need = rtb::collapse_to_wide(br.nodes, br.cell, mn.host);
-      if (stack_need > STACK_MAX) return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
-      rtb::reorder_top_breadth_first(mn.host, TOP_NODES);
+      std::shared_ptr<HostBuilt> hb = mi < s->host_built.size() ? s->host_built[mi] : nullptr;
+      if (!hb) {
+        hb = std::make_shared<HostBuilt>();
+        rtb::BuildResult br;
+        rtb::build_sah(h.p1.data(), h.p2.data(), h.p3.data(), h.ntris, max_leaf, br);
+        // the kernels walk four-wide nodes; a step leaves up to three children on the stack
+        hb->stack_need = rtb::collapse_to_wide(br.nodes, br.cell, hb->nodes);
+        rtb::reorder_top_breadth_first(hb->nodes, TOP_NODES);
+        for (int a = 0; a < 3; a++) {
+          hb->lo[a] = br.lo[a];
+          hb->hi[a] = br.hi[a];
+          hb->cell[a] = br.cell[a];
+        }
+        hb->scale = br.scale;
+        hb->tris.resize((size_t)h.ntris);
+        hb->trisf.resize((size_t)h.ntris);
+        hb->trin.resize((size_t)h.ntris);
+        for (int64_t k = 0; k < h.ntris; k++) {
+          uint32_t f = br.order[k];
+          DTri T;
+          DTriN TN;
+          double e1[3], e2[3];
+          for (int a = 0; a < 3; a++) {
+            T.p1[a] = h.p1[3 * f + a];
+            e1[a] = h.p2[3 * f + a] - h.p1[3 * f + a];
+            e2[a] = h.p3[3 * f + a] - h.p1[3 * f + a];
+            T.e1[a] = e1[a];
+            T.e2[a] = e2[a];
+          }
+          T.orig = f;
+          T.smooth = h.smooth[f];
+          if (T.smooth) {
+            for (int a = 0; a < 3; a++) {
+              TN.n[a] = h.n1[3 * f + a];
+              TN.n[3 + a] = h.n2[3 * f + a];
+              TN.n[6 + a] = h.n3[3 * f + a];
+            }
+          } else {
+            // triangle.rs:51: normalize(cross(e2, e1))
+            double cx = e2[1] * e1[2] - e2[2] * e1[1];
+            double cy = e2[2] * e1[0] - e2[0] * e1[2];
+            double cz = e2[0] * e1[1] - e2[1] * e1[0];
+            double mag = std::sqrt(cx * cx + cy * cy + cz * cz);
+            TN.n[0] = cx / mag;
+            TN.n[1] = cy / mag;
+            TN.n[2] = cz / mag;
+            for (int a = 3; a < 9; a++) TN.n[a] = 0.0;
+          }
+          DTriF TF;
+          for (int a = 0; a < 3; a++) {
+            TF.p1[a] = (float)T.p1[a];
+            TF.e1[a] = (float)T.e1[a];
+            TF.e2[a] = (float)T.e2[a];
+          }
+          TF.orig = T.orig;
+          uint32_t lo16[3];
+          for (int a = 0; a < 3; a++) {
+            const float r = (float)(T.p1[a] - (double)TF.p1[a]);  // what f32 lost
+            uint32_t bits;
+            std::memcpy(&bits, &r, sizeof bits);
+            lo16[a] = bits >> 16;  // truncated: at most 2^-7 of the residual is dropped
+          }
+          TF.p1_lo_xy = lo16[0] | (lo16[1] << 16);
+          TF.p1_lo_z = lo16[2];
+          hb->tris[(size_t)k] = T;
+          hb->trisf[(size_t)k] = TF;
+          hb->trin[(size_t)k] = TN;
+        }
+        if (s->keep_host_built) {
+          if (s->host_built.size() < s->meshes.size()) s->host_built.resize(s->meshes.size());
+          s->host_built[mi] = hb;
+        }
+      }
+      if (hb->stack_need > STACK_MAX) return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+      mn.host = hb->nodes;
       for (DNode4& N : mn.host)
         for (int k = 0; k < 4; k++)
           if (N.c[k] >= 0) N.c[k] += (int32_t)node_total;
       mn.count = (int)mn.host.size();
       for (int a = 0; a < 3; a++) {
-        M.lo[a] = br.lo[a];
-        M.hi[a] = br.hi[a];
-        M.cell[a] = br.cell[a];
+        M.lo[a] = hb->lo[a];
+        M.hi[a] = hb->hi[a];
+        M.cell[a] = hb->cell[a];
       }
-      M.scale = br.scale;
-      std::vector<DTri> tris((size_t)h.ntris);
-      std::vector<DTriF> trisf((size_t)h.ntris);
-      std::vector<DTriN> trin((size_t)h.ntris);
-      for (int64_t k = 0; k < h.ntris; k++) {
-        uint32_t f = br.order[k];
-        DTri T;
-        DTriN TN;
-        double e1[3], e2[3];
-        for (int a = 0; a < 3; a++) {
-          T.p1[a] = h.p1[3 * f + a];
-          e1[a] = h.p2[3 * f + a] - h.p1[3 * f + a];
-          e2[a] = h.p3[3 * f + a] - h.p1[3 * f + a];
-          T.e1[a] = e1[a];
-          T.e2[a] = e2[a];
-        }
-        T.orig = f;
-        T.smooth = h.smooth[f];
-        if (T.smooth) {
-          for (int a = 0; a < 3; a++) {
-            TN.n[a] = h.n1[3 * f + a];
-            TN.n[3 + a] = h.n2[3 * f + a];
-            TN.n[6 + a] = h.n3[3 * f + a];
-          }
-        } else {
-          // triangle.rs:51: normalize(cross(e2, e1))
-          double cx = e2[1] * e1[2] - e2[2] * e1[1];
-          double cy = e2[2] * e1[0] - e2[0] * e1[2];
-          double cz = e2[0] * e1[1] - e2[1] * e1[0];
-          double mag = std::sqrt(cx * cx + cy * cy + cz * cz);
-          TN.n[0] = cx / mag;
-          TN.n[1] = cy / mag;
-          TN.n[2] = cz / mag;
-          for (int a = 3; a < 9; a++) TN.n[a] = 0.0;
-        }
-        DTriF TF;
-        for (int a = 0; a < 3; a++) {
-          TF.p1[a] = (float)T.p1[a];
-          TF.e1[a] = (float)T.e1[a];
-          TF.e2[a] = (float)T.e2[a];
-        }
-        TF.orig = T.orig;
-        uint32_t lo16[3];
-        for (int a = 0; a < 3; a++) {
-          const float r = (float)(T.p1[a] - (double)TF.p1[a]);  // what f32 lost
-          uint32_t bits;
-          std::memcpy(&bits, &r, sizeof bits);
-          lo16[a] = bits >> 16;  // truncated: at most 2^-7 of the residual is dropped
-        }
-        TF.p1_lo_xy = lo16[0] | (lo16[1] << 16);
-        TF.p1_lo_z = lo16[2];
-        tris[(size_t)k] = T;
-        trisf[(size_t)k] = TF;
-        trin[(size_t)k] = TN;
-      }
+      M.scale = hb->scale;
       if (h.ntris > 0) {
-        HIP_TRY(hipMemcpy(d_tris + tri_total, tris.data(), tris.size() * sizeof(DTri), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_trisf + tri_total, trisf.data(), trisf.size() * sizeof(DTriF), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_trin + tri_total, trin.data(), trin.size() * sizeof(DTriN), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_tris + tri_total, hb->tris.data(), hb->tris.size() * sizeof(DTri), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_trisf + tri_total, hb->trisf.data(), hb->trisf.size() * sizeof(DTriF), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_trin + tri_total, hb->trin.data(), hb->trin.size() * sizeof(DTriN), hipMemcpyHostToDevice));
       }
     }
     M.n_nodes = mn.count;
@@ -1490,6 +1547,7 @@ static void resolve_estimate(rt_scene* s, rt_scene::WfState* w, int* complete) {
   }
   rt_scene::WfPlan plan;
   plan.key = w->estimate_key;
+  plan.id = w->estimate_id;
   plan.depth = w->estimate_depth;
   plan.fast = w->estimate_fast;
   plan.n[0] = plan.front[0] = w->estimate_n0;
@@ -1501,7 +1559,7 @@ static void resolve_estimate(rt_scene* s, rt_scene::WfState* w, int* complete) {
     plan.levels = l + 1;
   }
   for (size_t i = 0; i < s->wf_plans.size(); i++)
-    if (s->wf_plans[i].key == plan.key) {
+    if (s->wf_plans[i].key == plan.key && same_frame(s->wf_plans[i].id, plan.id)) {
       s->wf_plans.erase(s->wf_plans.begin() + (long)i);
       break;
     }
@@ -1513,10 +1571,11 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
                             int depth, double* d_f64, uint8_t* d_u8, hipStream_t st, bool stats,
                             bool fast) {
   const uint64_t key = frame_key(dc, pm, depth, fast);
+  const FrameId id = frame_id(dc, pm.tile_first, pm.tile_step, depth, fast, false);
   rt_scene::WfPlan plan;  // a copy: the list may be reordered below
   bool planned = false;
   for (size_t i = 0; i < s->wf_plans.size(); i++)
-    if (s->wf_plans[i].key == key) {
+    if (s->wf_plans[i].key == key && same_frame(s->wf_plans[i].id, id)) {
       plan = s->wf_plans[i];
       planned = true;
       // most recently rendered last: the oldest is the one forgotten, the newest the one
@@ -1527,6 +1586,7 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     }
   if (!planned) {
     plan.key = key;
+    plan.id = id;
     plan.depth = depth;
     plan.fast = fast;
     plan.n[0] = plan.front[0] = ntiles * (long long)(RT_TILE * RT_TILE);
@@ -1705,6 +1765,7 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     w->estimate_pending = true;
     s->n_estimated++;
     w->estimate_key = key;
+    w->estimate_id = id;
     w->estimate_depth = depth;
     w->estimate_n0 = level_n[0];
     w->estimate_fast = fast;
@@ -1737,9 +1798,13 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
   return RT_OK;
 }
 
+// `compact`: a shard of ONE (tile_step 1) still goes to a compact tile buffer instead of the
+// row-major image — what rt_render_multi asks for, whose one shard of one is stitched like any
+// other.  The flag belongs to the call, not to the scene: the single-GPU entry points render a
+// scene committed with rt_scene_commit_multi row-major like any other scene.
 static int render_device_fixed(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline,
                                int tile_first, int tile_step, double* d_rgb_f64, uint8_t* d_rgb_u8,
-                               void* hip_stream, int want_stats) {
+                               void* hip_stream, int want_stats, bool compact) {
   if (!s || !cam) return fail(RT_ERR_ARG, "null argument");
   if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
   if (mode != RT_MODE_F64_PARITY && mode != RT_MODE_F32_FAST) return fail(RT_ERR_ARG, "unknown mode");
@@ -1758,7 +1823,7 @@ static int render_device_fixed(rt_scene* s, const rt_camera* cam, int depth, int
   if (ntiles < 0) return fail(RT_ERR_ARG, "bad tile shard");
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   HIP_TRY(hipSetDevice(s->device));
-  const PixelMap pm = pixel_map(cam, tile_first, tile_step, s->compact_always);
+  const PixelMap pm = pixel_map(cam, tile_first, tile_step, compact);
   if (want_stats) HIP_TRY(hipMemsetAsync(s->d_counters, 0, (N_COUNTERS + 1) * sizeof(unsigned long long), st));
   HIP_TRY(hipEventRecord(s->ev0, st));
   s->launches = 0;
@@ -1781,8 +1846,9 @@ static int render_device_fixed(rt_scene* s, const rt_camera* cam, int depth, int
       bool deep = false;
       if (one_stream) {
         const uint64_t whole = frame_key(dc, pm, depth, mode == RT_MODE_F32_FAST);
+        const FrameId whole_id = frame_id(dc, pm.tile_first, pm.tile_step, depth, mode == RT_MODE_F32_FAST, false);
         for (const rt_scene::WfPlan& c : s->wf_plans)
-          if (c.key == whole) {
+          if (c.key == whole && same_frame(c.id, whole_id)) {
             long long below = 0;
             for (int l = 1; l < c.levels; l++) below += c.n[l];
             deep = below >= c.n[0];
@@ -2050,26 +2116,27 @@ extern "C" {
 // RT_PIPELINE_AUTO: the first time a frame (camera, shard, depth, mode) is seen it is rendered
 // once with each pipeline and timed with HIP events (both write the same bits); the faster
 // one is remembered for that frame.
-int rt_render_device(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline,
-                     int tile_first, int tile_step, double* d_rgb_f64, uint8_t* d_rgb_u8,
-                     void* hip_stream, int want_stats) {
+static int render_device_any(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline,
+                             int tile_first, int tile_step, double* d_rgb_f64, uint8_t* d_rgb_u8,
+                             void* hip_stream, int want_stats, bool compact) {
   if (pipeline != RT_PIPELINE_AUTO)
     return render_device_fixed(s, cam, depth, mode, pipeline, tile_first, tile_step, d_rgb_f64, d_rgb_u8,
-                               hip_stream, want_stats);
+                               hip_stream, want_stats, compact);
   if (!s || !cam) return fail(RT_ERR_ARG, "null argument");
   if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
   if (mode == RT_MODE_F32_FAST || depth == 0)  // one pipeline serves these
     return render_device_fixed(s, cam, depth, mode, depth == 0 ? RT_PIPELINE_MEGAKERNEL : RT_PIPELINE_WAVEFRONT,
-                               tile_first, tile_step, d_rgb_f64, d_rgb_u8, hip_stream, want_stats);
+                               tile_first, tile_step, d_rgb_f64, d_rgb_u8, hip_stream, want_stats, compact);
   DCamera dc;
   int rc = camera_to_device(cam, dc);
   if (rc) return rc;
-  const PixelMap pm = pixel_map(cam, tile_first, tile_step, s->compact_always);
+  const PixelMap pm = pixel_map(cam, tile_first, tile_step, compact);
   const uint64_t key = frame_key(dc, pm, depth, false);
+  const FrameId id = frame_id(dc, tile_first, tile_step, depth, false, compact);
   for (const auto& kv : s->auto_choice)
-    if (kv.first == key)
-      return render_device_fixed(s, cam, depth, mode, kv.second, tile_first, tile_step, d_rgb_f64, d_rgb_u8,
-                                 hip_stream, want_stats);
+    if (kv.key == key && same_frame(kv.id, id))
+      return render_device_fixed(s, cam, depth, mode, kv.pipeline, tile_first, tile_step, d_rgb_f64, d_rgb_u8,
+                                 hip_stream, want_stats, compact);
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   float best_ms = 0.f;
   int best = RT_PIPELINE_WAVEFRONT;
@@ -2078,7 +2145,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, int depth, int mode, int
     float ms = 0.f;
     for (int rep = 0; rep < 2; rep++) {  // the first run of a pipeline sizes its buffers
       rc = render_device_fixed(s, cam, depth, mode, candidates[c], tile_first, tile_step, d_rgb_f64, d_rgb_u8,
-                               hip_stream, 0);
+                               hip_stream, 0, compact);
       if (rc) return rc;
       HIP_TRY(hipStreamSynchronize(st));
       HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
@@ -2088,9 +2155,16 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, int depth, int mode, int
       best = candidates[c];
     }
   }
-  s->auto_choice.push_back({key, best});
+  s->auto_choice.push_back({key, id, best});
   return render_device_fixed(s, cam, depth, mode, best, tile_first, tile_step, d_rgb_f64, d_rgb_u8, hip_stream,
-                             want_stats);
+                             want_stats, compact);
+}
+
+int rt_render_device(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline,
+                     int tile_first, int tile_step, double* d_rgb_f64, uint8_t* d_rgb_u8,
+                     void* hip_stream, int want_stats) {
+  return render_device_any(s, cam, depth, mode, pipeline, tile_first, tile_step, d_rgb_f64, d_rgb_u8, hip_stream,
+                           want_stats, false);
 }
 
 int rt_render_stats(rt_scene* s, rt_stats* st) {
@@ -2161,8 +2235,10 @@ int rt_render(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeli
   return RT_OK;
 }
 
-int rt_detile_u8(const uint8_t* d_tiles, int nshards, int64_t tiles_per_shard, int hsize, int vsize,
-                 uint8_t* d_image, void* hip_stream) {
+}  // extern "C"
+template <typename T>
+static int detile_any(const T* d_tiles, int nshards, int64_t tiles_per_shard, int hsize, int vsize, T* d_image,
+                      void* hip_stream) {
   if (!d_tiles || !d_image || nshards <= 0 || hsize <= 0 || vsize <= 0 || tiles_per_shard < 0)
     return fail(RT_ERR_ARG, "bad argument");
   int tiles_x = (hsize + RT_TILE - 1) / RT_TILE;
@@ -2171,10 +2247,19 @@ int rt_detile_u8(const uint8_t* d_tiles, int nshards, int64_t tiles_per_shard, i
     return fail(RT_ERR_ARG, "tiles_per_shard too small for this image");
   long long npx = (long long)hsize * vsize;
   dim3 block(256), grid((unsigned)((npx + 255) / 256));
-  hipLaunchKernelGGL(k_detile_u8, grid, block, 0, static_cast<hipStream_t>(hip_stream), d_tiles,
+  hipLaunchKernelGGL(k_detile<T>, grid, block, 0, static_cast<hipStream_t>(hip_stream), d_tiles,
                      nshards, (long long)tiles_per_shard, hsize, vsize, tiles_x, d_image);
   HIP_TRY(hipGetLastError());
   return RT_OK;
+}
+extern "C" {
+int rt_detile_u8(const uint8_t* d_tiles, int nshards, int64_t tiles_per_shard, int hsize, int vsize,
+                 uint8_t* d_image, void* hip_stream) {
+  return detile_any(d_tiles, nshards, tiles_per_shard, hsize, vsize, d_image, hip_stream);
+}
+int rt_detile_f64(const double* d_tiles, int nshards, int64_t tiles_per_shard, int hsize, int vsize,
+                  double* d_image, void* hip_stream) {
+  return detile_any(d_tiles, nshards, tiles_per_shard, hsize, vsize, d_image, hip_stream);
 }
 
 int rt_trace_rays(rt_scene* s, int64_t n, const double* origins, const double* directions,
@@ -2209,7 +2294,7 @@ int rt_trace_rays(rt_scene* s, int64_t n, const double* origins, const double* d
 // every GPU, the frame's 32x32-pixel tiles are dealt round-robin to the GPUs (bands would be
 // badly balanced: glass pixels cost several times what floor pixels do), and ONE exchange ends
 // the frame: every GPU sends its compact tile buffer to the first one (grouped ncclSend/ncclRecv:
-// each peer has its own xGMI link into it), which stitches them (k_detile_u8).
+// each peer has its own xGMI link into it), which stitches them (k_detile).
 // RCCL is loaded when the first multi-GPU scene is committed (dlopen), so a process that
 // renders on one GPU through the other entry points never touches it.
 struct Rccl {
@@ -2263,6 +2348,22 @@ struct Multi {
   size_t all_cap = 0;
   uint8_t* d_image = nullptr;     // first GPU: the stitched image, when the caller gave no device buffer
   size_t image_cap = 0;
+  // the same three for the f64 colours (allocated when a frame first asks for them)
+  std::vector<double*> d_tiles_f64;
+  size_t tiles_f64_cap = 0;
+  double* d_all_f64 = nullptr;
+  size_t all_f64_cap = 0;
+  double* d_image_f64 = nullptr;
+  size_t image_f64_cap = 0;
+  // Frames this scene has rendered before: their queue lengths (or pipeline choice) are known on
+  // every GPU, so the shards are issued one after the other without any wait.  A frame not in
+  // this list is planned with read-backs per recursion level; its shards are issued by one host
+  // thread per GPU, so the GPUs plan side by side instead of one after the other.
+  struct Seen {
+    FrameId id;
+    int pipeline;
+  };
+  std::vector<Seen> seen;
   bool ready = false;             // rt_scene_commit_multi ran to its end
 };
 
@@ -2287,15 +2388,56 @@ static void multi_destroy(Multi* m) {
     if (d < m->comms.size() && m->comms[d] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comms[d]);
     if (d < m->streams.size() && m->streams[d]) (void)hipStreamDestroy(m->streams[d]);
     if (d < m->d_tiles.size() && m->d_tiles[d]) (void)hipFree(m->d_tiles[d]);
+    if (d < m->d_tiles_f64.size() && m->d_tiles_f64[d]) (void)hipFree(m->d_tiles_f64[d]);
     if (d == 0) {
       if (m->d_all) (void)hipFree(m->d_all);
       if (m->d_image) (void)hipFree(m->d_image);
+      if (m->d_all_f64) (void)hipFree(m->d_all_f64);
+      if (m->d_image_f64) (void)hipFree(m->d_image_f64);
     }
     if (d > 0 && d < m->scenes.size() && m->scenes[d]) rt_scene_destroy(m->scenes[d]);
   }
   (void)hipSetDevice(cur);
   delete m;
 }
+
+}  // extern "C"
+// Runs job(d) for d = first .. ndev-1, each on a host thread of its own with devs[d] current,
+// and returns the first failure (its message becomes the caller's rt_last_error()).
+template <typename Job>
+static int per_device_threads(const std::vector<int>& devs, int first, Job job) {
+  const int ndev = (int)devs.size();
+  std::vector<int> rcs((size_t)ndev, RT_OK);
+  std::vector<std::string> errs((size_t)ndev);
+  std::vector<std::thread> threads;
+  for (int d = first; d < ndev; d++)
+    threads.emplace_back([&, d]() {
+      if (hipSetDevice(devs[(size_t)d]) != hipSuccess) {
+        rcs[(size_t)d] = RT_ERR_HIP;
+        errs[(size_t)d] = "hipSetDevice failed";
+        return;
+      }
+      rcs[(size_t)d] = job(d);
+      if (rcs[(size_t)d]) errs[(size_t)d] = g_err;  // the error text is thread-local
+    });
+  for (std::thread& t : threads) t.join();
+  for (int d = first; d < ndev; d++)
+    if (rcs[(size_t)d]) return fail(rcs[(size_t)d], "GPU " + std::to_string(devs[(size_t)d]) + ": " + errs[(size_t)d]);
+  return RT_OK;
+}
+// grow-only device buffer on the current device; *cap is 0 while the pointer is not valid
+template <typename T>
+static int multi_ensure(T** p, size_t* cap, size_t need, hipStream_t wait_for) {
+  if (need <= *cap && *p) return RT_OK;
+  HIP_TRY(hipStreamSynchronize(wait_for));
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  HIP_TRY(hipMalloc((void**)p, need * sizeof(T)));
+  *cap = need;
+  return RT_OK;
+}
+extern "C" {
 
 int rt_scene_commit_multi(rt_scene* s, const int* device_ids, int ndev, int bvh_builder) {
   if (!s || !device_ids) return fail(RT_ERR_ARG, "null argument");
@@ -2316,6 +2458,16 @@ int rt_scene_commit_multi(rt_scene* s, const int* device_ids, int ndev, int bvh_
   m->scenes.assign((size_t)ndev, nullptr);
   m->scenes[0] = s;
   s->multi = m;  // from here on rt_scene_destroy(s) releases everything below
+  // The first GPU's commit builds the host-built trees and keeps them; the replicas upload those
+  // (one host thread per GPU, side by side) instead of building them again.  Meshes that go to the
+  // device builder are built on every GPU, also side by side.
+  s->keep_host_built = true;
+  rc = rt_scene_commit(s, m->devs[0], bvh_builder);
+  s->keep_host_built = false;
+  if (rc) {
+    s->host_built.clear();
+    return rc;
+  }
   for (int d = 1; d < ndev; d++) {  // replicas: the same description, committed to the other GPUs
     rt_scene* r = new rt_scene();
     r->mats = s->mats;
@@ -2325,20 +2477,22 @@ int rt_scene_commit_multi(rt_scene* s, const int* device_ids, int ndev, int bvh_
     r->meshes = s->meshes;
     r->lights = s->lights;
     r->next_order = s->next_order;
+    r->host_built = s->host_built;
     m->scenes[(size_t)d] = r;
   }
-  for (int d = 0; d < ndev; d++) {
+  rc = per_device_threads(m->devs, 1, [&](int d) { return rt_scene_commit(m->scenes[(size_t)d], m->devs[(size_t)d], bvh_builder); });
+  s->host_built.clear();
+  for (int d = 1; d < ndev; d++) {
     rt_scene* r = m->scenes[(size_t)d];
-    if ((rc = rt_scene_commit(r, m->devs[(size_t)d], bvh_builder))) return rc;
-    r->compact_always = true;
-    if (d > 0) {  // a replica's host copy of the geometry has served its purpose
-      std::vector<MeshH>().swap(r->meshes);
-    }
+    r->host_built.clear();
+    std::vector<MeshH>().swap(r->meshes);  // a replica's host copy of the geometry has served its purpose
   }
+  if (rc) return rc;
   m->comms.assign((size_t)ndev, nullptr);
   NCCL_TRY(g_rccl.CommInitAll(m->comms.data(), ndev, m->devs.data()));
   m->streams.assign((size_t)ndev, nullptr);
   m->d_tiles.assign((size_t)ndev, nullptr);
+  m->d_tiles_f64.assign((size_t)ndev, nullptr);
   for (int d = 0; d < ndev; d++) {
     HIP_TRY(hipSetDevice(m->devs[(size_t)d]));
     HIP_TRY(hipStreamCreateWithFlags(&m->streams[(size_t)d], hipStreamNonBlocking));
@@ -2349,79 +2503,119 @@ int rt_scene_commit_multi(rt_scene* s, const int* device_ids, int ndev, int bvh_
 
 int rt_scene_device_count(const rt_scene* s) {
   if (!s || !s->committed) return 0;
-  if (s->multi && !s->multi->ready) return 0;  // a multi-GPU commit that failed half way: only destroy is left
+  if (s->multi && !s->multi->ready) return 0;  // a multi-GPU commit that failed half way
   return s->multi ? (int)s->multi->devs.size() : 1;
 }
 
-int rt_render_multi(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline, uint8_t* out_rgb_u8,
-                    uint8_t* d_rgb_u8, rt_stats* stats) {
+int rt_render_multi_f64(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline, double* out_rgb_f64,
+                        double* d_rgb_f64, uint8_t* out_rgb_u8, uint8_t* d_rgb_u8, rt_stats* stats) {
   if (!s || !cam) return fail(RT_ERR_ARG, "null argument");
   if (!s->committed || !s->multi || !s->multi->ready)
     return fail(RT_ERR_STATE, "scene not committed with rt_scene_commit_multi (or that commit failed)");
   if (cam->hsize <= 0 || cam->vsize <= 0) return fail(RT_ERR_ARG, "camera size must be positive");
-  if (!out_rgb_u8 && !d_rgb_u8) return fail(RT_ERR_ARG, "no output buffer");
+  const bool want_u8 = out_rgb_u8 || d_rgb_u8, want_f64 = out_rgb_f64 || d_rgb_f64;
+  if (!want_u8 && !want_f64) return fail(RT_ERR_ARG, "no output buffer");
+  DCamera dc;
+  int rc = camera_to_device(cam, dc);
+  if (rc) return rc;
   Multi* m = s->multi;
   const int ndev = (int)m->devs.size();
   auto t0 = std::chrono::steady_clock::now();
   CurrentDeviceKeeper keep;
   int64_t per = 0;
   for (int d = 0; d < ndev; d++) per = std::max(per, rt_shard_tiles(cam->hsize, cam->vsize, d, ndev));
-  const size_t bytes_per = (size_t)per * RT_TILE * RT_TILE * 3;
+  const size_t elems_per = (size_t)per * RT_TILE * RT_TILE * 3;  // colour components per shard buffer
   const size_t npx = (size_t)cam->hsize * cam->vsize;
-  if (bytes_per > m->tiles_cap) {
+  // Each capacity is zeroed before its buffers are touched: an allocation that fails half way
+  // leaves nothing behind that a later call would trust.
+  if (want_u8 && elems_per > m->tiles_cap) {
+    m->tiles_cap = 0;
     for (int d = 0; d < ndev; d++) {
       HIP_TRY(hipSetDevice(m->devs[(size_t)d]));
-      HIP_TRY(hipStreamSynchronize(m->streams[(size_t)d]));
-      if (m->d_tiles[(size_t)d]) (void)hipFree(m->d_tiles[(size_t)d]);
-      m->d_tiles[(size_t)d] = nullptr;
-      HIP_TRY(hipMalloc((void**)&m->d_tiles[(size_t)d], bytes_per));
+      size_t cap = 0;
+      if ((rc = multi_ensure(&m->d_tiles[(size_t)d], &cap, elems_per, m->streams[(size_t)d]))) return rc;
     }
-    m->tiles_cap = bytes_per;
+    m->tiles_cap = elems_per;
+  }
+  if (want_f64 && elems_per > m->tiles_f64_cap) {
+    m->tiles_f64_cap = 0;
+    for (int d = 0; d < ndev; d++) {
+      HIP_TRY(hipSetDevice(m->devs[(size_t)d]));
+      size_t cap = 0;
+      if ((rc = multi_ensure(&m->d_tiles_f64[(size_t)d], &cap, elems_per, m->streams[(size_t)d]))) return rc;
+    }
+    m->tiles_f64_cap = elems_per;
   }
   HIP_TRY(hipSetDevice(m->devs[0]));
-  if (bytes_per * (size_t)ndev > m->all_cap) {
-    HIP_TRY(hipStreamSynchronize(m->streams[0]));
-    if (m->d_all) (void)hipFree(m->d_all);
-    m->d_all = nullptr;
-    m->all_cap = 0;
-    HIP_TRY(hipMalloc((void**)&m->d_all, bytes_per * (size_t)ndev));
-    m->all_cap = bytes_per * (size_t)ndev;
-  }
   uint8_t* image = d_rgb_u8;
-  if (!image) {
-    if (npx * 3 > m->image_cap) {
-      HIP_TRY(hipStreamSynchronize(m->streams[0]));
-      if (m->d_image) (void)hipFree(m->d_image);
-      m->d_image = nullptr;
-      m->image_cap = 0;
-      HIP_TRY(hipMalloc((void**)&m->d_image, npx * 3));
-      m->image_cap = npx * 3;
+  double* image_f64 = d_rgb_f64;
+  if (want_u8) {
+    if ((rc = multi_ensure(&m->d_all, &m->all_cap, elems_per * (size_t)ndev, m->streams[0]))) return rc;
+    if (!image) {
+      if ((rc = multi_ensure(&m->d_image, &m->image_cap, npx * 3, m->streams[0]))) return rc;
+      image = m->d_image;
     }
-    image = m->d_image;
+  }
+  if (want_f64) {
+    if ((rc = multi_ensure(&m->d_all_f64, &m->all_f64_cap, elems_per * (size_t)ndev, m->streams[0]))) return rc;
+    if (!image_f64) {
+      if ((rc = multi_ensure(&m->d_image_f64, &m->image_f64_cap, npx * 3, m->streams[0]))) return rc;
+      image_f64 = m->d_image_f64;
+    }
   }
   // every GPU renders its tiles (scene replicated, no communication) ...
-  int rc;
-  for (int d = 0; d < ndev; d++) {
-    HIP_TRY(hipSetDevice(m->devs[(size_t)d]));
-    if ((rc = rt_render_device(m->scenes[(size_t)d], cam, depth, mode, pipeline, d, ndev, nullptr, m->d_tiles[(size_t)d],
-                               m->streams[(size_t)d], stats ? 1 : 0)))
-      return rc;
+  const FrameId id = frame_id(dc, 0, ndev, depth, mode == RT_MODE_F32_FAST, true);
+  bool seen = false;
+  for (const Multi::Seen& q : m->seen) seen = seen || (q.pipeline == pipeline && same_frame(q.id, id));
+  auto issue = [&](int d) {
+    return render_device_any(m->scenes[(size_t)d], cam, depth, mode, pipeline, d, ndev,
+                             want_f64 ? m->d_tiles_f64[(size_t)d] : nullptr, want_u8 ? m->d_tiles[(size_t)d] : nullptr,
+                             m->streams[(size_t)d], stats ? 1 : 0, true);
+  };
+  if (seen || ndev == 1) {
+    for (int d = 0; d < ndev; d++) {
+      HIP_TRY(hipSetDevice(m->devs[(size_t)d]));
+      if ((rc = issue(d))) return rc;
+    }
+  } else {
+    // a frame not rendered before costs a host read-back per recursion level (or the timing runs
+    // of RT_PIPELINE_AUTO) on every GPU: one host thread per GPU, so they plan side by side
+    if ((rc = per_device_threads(m->devs, 0, issue))) return rc;
+  }
+  if (!seen) {
+    if (m->seen.size() >= 64) m->seen.erase(m->seen.begin());
+    m->seen.push_back({id, pipeline});
   }
   // ... and ONE exchange: all shards to the first GPU.  The first GPU's own shard travels the
   // same way (a send to itself), so one GPU alone runs the code path of eight.
   NCCL_TRY(g_rccl.GroupStart());
   for (int d = 0; d < ndev; d++) {
-    ncclResult_t r1 = g_rccl.Send(m->d_tiles[(size_t)d], bytes_per, ncclUint8, 0, m->comms[(size_t)d], m->streams[(size_t)d]);
-    ncclResult_t r2 = g_rccl.Recv(m->d_all + (size_t)d * bytes_per, bytes_per, ncclUint8, d, m->comms[0], m->streams[0]);
-    if (r1 != ncclSuccess || r2 != ncclSuccess) {
-      (void)g_rccl.GroupEnd();
-      return fail(RT_ERR_HIP, std::string("ncclSend/ncclRecv: ") + g_rccl.GetErrorString(r1 != ncclSuccess ? r1 : r2));
+    ncclResult_t r1 = ncclSuccess, r2 = ncclSuccess, r3 = ncclSuccess, r4 = ncclSuccess;
+    if (want_u8) {
+      r1 = g_rccl.Send(m->d_tiles[(size_t)d], elems_per, ncclUint8, 0, m->comms[(size_t)d], m->streams[(size_t)d]);
+      r2 = g_rccl.Recv(m->d_all + (size_t)d * elems_per, elems_per, ncclUint8, d, m->comms[0], m->streams[0]);
     }
+    if (want_f64) {
+      r3 = g_rccl.Send(m->d_tiles_f64[(size_t)d], elems_per, ncclDouble, 0, m->comms[(size_t)d], m->streams[(size_t)d]);
+      r4 = g_rccl.Recv(m->d_all_f64 + (size_t)d * elems_per, elems_per, ncclDouble, d, m->comms[0], m->streams[0]);
+    }
+    for (ncclResult_t r : {r1, r2, r3, r4})
+      if (r != ncclSuccess) {
+        (void)g_rccl.GroupEnd();
+        return fail(RT_ERR_HIP, std::string("ncclSend/ncclRecv: ") + g_rccl.GetErrorString(r));
+      }
   }
   NCCL_TRY(g_rccl.GroupEnd());
   HIP_TRY(hipSetDevice(m->devs[0]));
-  if ((rc = rt_detile_u8(m->d_all, ndev, per, cam->hsize, cam->vsize, image, m->streams[0]))) return rc;
-  if (out_rgb_u8) HIP_TRY(hipMemcpyAsync(out_rgb_u8, image, npx * 3, hipMemcpyDeviceToHost, m->streams[0]));
+  if (want_u8) {
+    if ((rc = rt_detile_u8(m->d_all, ndev, per, cam->hsize, cam->vsize, image, m->streams[0]))) return rc;
+    if (out_rgb_u8) HIP_TRY(hipMemcpyAsync(out_rgb_u8, image, npx * 3, hipMemcpyDeviceToHost, m->streams[0]));
+  }
+  if (want_f64) {
+    if ((rc = rt_detile_f64(m->d_all_f64, ndev, per, cam->hsize, cam->vsize, image_f64, m->streams[0]))) return rc;
+    if (out_rgb_f64)
+      HIP_TRY(hipMemcpyAsync(out_rgb_f64, image_f64, npx * 3 * sizeof(double), hipMemcpyDeviceToHost, m->streams[0]));
+  }
   for (int d = ndev - 1; d >= 0; d--) {
     HIP_TRY(hipSetDevice(m->devs[(size_t)d]));
     HIP_TRY(hipStreamSynchronize(m->streams[(size_t)d]));
@@ -2453,6 +2647,12 @@ int rt_render_multi(rt_scene* s, const rt_camera* cam, int depth, int mode, int 
     stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   return RT_OK;
+}
+
+int rt_render_multi(rt_scene* s, const rt_camera* cam, int depth, int mode, int pipeline, uint8_t* out_rgb_u8,
+                    uint8_t* d_rgb_u8, rt_stats* stats) {
+  if (!out_rgb_u8 && !d_rgb_u8) return fail(RT_ERR_ARG, "no output buffer");
+  return rt_render_multi_f64(s, cam, depth, mode, pipeline, nullptr, nullptr, out_rgb_u8, d_rgb_u8, stats);
 }
 
 }  // extern "C"

@@ -705,8 +705,8 @@ Canvas render(const Camera& camera, DeviceScene& scene, const RenderOptions& opt
   rt_camera cam = camera.to_abi();
   int rc;
   if (scene.multi()) {
-    if (opt.keep_f64) throw std::runtime_error("render: a frame over several GPUs is delivered quantised only");
-    rc = rt_render_multi(scene.handle(), &cam, opt.depth, opt.mode, opt.pipeline, c.rgb8.data(), nullptr, opt.stats);
+    rc = rt_render_multi_f64(scene.handle(), &cam, opt.depth, opt.mode, opt.pipeline,
+                             opt.keep_f64 ? c.rgb.data() : nullptr, nullptr, c.rgb8.data(), nullptr, opt.stats);
   } else {
     rc = rt_render(scene.handle(), &cam, opt.depth, opt.mode, opt.pipeline,
                    opt.keep_f64 ? c.rgb.data() : nullptr, c.rgb8.data(), opt.stats);

@@ -243,11 +243,8 @@ int rth_render(rth_world* w, int depth, int mode, int pipeline, double* out_rgb_
     rt_camera cam = w->camera.to_abi();
     int rc;
     if (w->device.multi()) {
-      if (out_rgb_f64) {
-        g_herr = "a frame over several GPUs is delivered quantised only";
-        return -1;
-      }
-      rc = rt_render_multi(w->device.handle(), &cam, depth, mode, pipeline, out_rgb_u8, nullptr, stats);
+      rc = rt_render_multi_f64(w->device.handle(), &cam, depth, mode, pipeline, out_rgb_f64, nullptr, out_rgb_u8,
+                               nullptr, stats);
     } else {
       rc = rt_render(w->device.handle(), &cam, depth, mode, pipeline, out_rgb_f64, out_rgb_u8, stats);
     }

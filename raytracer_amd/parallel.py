@@ -33,11 +33,19 @@ def shard_pixel_coords(hsize, vsize, rank, nranks):
     return py, px, (py < vsize) & (px < hsize)
 
 
-def gather_tiles(tiles, rank, nranks, dist, dst=0):
+def gather_tiles(tiles, rank, nranks, dist, dst=0, out=None):
     """One gather of equal-sized per-rank tile buffers to `dst`.  Returns the list of buffers
-    on dst (index = source rank), None elsewhere."""
+    on dst (index = source rank), None elsewhere.  `out` (on dst): the buffers to receive into,
+    e.g. the rows of one contiguous (nranks, n) buffer that rt_detile_u8 then reads; new
+    buffers are made when it is None."""
     import torch
-    out = [torch.empty_like(tiles) for _ in range(nranks)] if rank == dst else None
+    if rank == dst:
+        if out is None:
+            out = [torch.empty_like(tiles) for _ in range(nranks)]
+        if len(out) != nranks or any(o.numel() != tiles.numel() for o in out):
+            raise ValueError("gather_tiles: need one receive buffer of the shard's size per rank")
+    else:
+        out = None
     dist.gather(tiles, out, dst=dst)
     return out
 

@@ -29,7 +29,11 @@ def _worker(rank, world, port, hs, vs, q):
     buf[:py.shape[0]][ok] = pixel_value(py[ok], px[ok])
     t = torch.from_numpy(buf.reshape(-1))
     got = parallel.gather_tiles(t, rank, world, dist)
+    # ... and as bench.py calls it: received straight into the rows of one contiguous buffer
+    rows = torch.zeros((world, t.numel()), dtype=torch.uint8) if rank == 0 else None
+    parallel.gather_tiles(t, rank, world, dist, out=list(rows.unbind(0)) if rank == 0 else None)
     if rank == 0:
+        assert all(torch.equal(rows[r], got[r]) for r in range(world))
         shards = [g.numpy().reshape(per, rt.TILE, rt.TILE, 3) for g in got]
         img = parallel.detile_reference(shards, hs, vs)
         yy, xx = np.meshgrid(np.arange(vs), np.arange(hs), indexing="ij")
