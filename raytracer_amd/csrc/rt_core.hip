@@ -109,6 +109,8 @@ struct rt_scene {
     void* wf_tasks[MAX_DEPTH + 1] = {};
     void* wf_nodes[MAX_DEPTH + 1] = {};
     void* wf_live[MAX_DEPTH + 1] = {};  // one byte per node: 1 = children will add to it
+    void* wf_shadow[MAX_DEPTH + 1] = {};  // the level's queued light loops (WfShadow), one per hit
+    size_t wf_shadow_cap[MAX_DEPTH + 1] = {};
     void* wf_keys[MAX_DEPTH + 1] = {};  // coherence sort: key per task slot / task slot per sorted position
     void* wf_perm[MAX_DEPTH + 1] = {};
     size_t wf_keys_cap[MAX_DEPTH + 1] = {};
@@ -117,7 +119,7 @@ struct rt_scene {
     size_t wf_task_cap[MAX_DEPTH + 1] = {};
     size_t wf_node_cap[MAX_DEPTH + 1] = {};
     size_t wf_live_cap[MAX_DEPTH + 1] = {};
-    unsigned int* wf_counts = nullptr;       // device, two counters per level
+    unsigned int* wf_counts = nullptr;       // device: two counters per level, the overflow flag, then one shadow-queue length per level
     unsigned int* wf_counts_host = nullptr;  // pinned
     // a frame issued on an estimate whose counters are on their way to wf_counts_host
     bool estimate_pending = false;
@@ -157,6 +159,14 @@ struct rt_scene {
   };
   std::vector<AutoChoice> auto_choice;  // frame -> pipeline picked by RT_PIPELINE_AUTO
   bool share_leaves = true;
+  // RT_SHADOW_PASS=1: the light loops of a level's hits run as a pass of their own over a
+  // compacted queue (full waves, nothing parked in scratch while a shadow walk runs; the pass
+  // rides behind the next level's waves in that level's launch) instead of inside the level
+  // kernel.  Same frames.  Off by default: measured on MI355X the queue's traffic and the second
+  // set-up of every hit cost more than the idle lanes it removes (pawn 1080p 2.54 vs 2.42 ms,
+  // pawn 8K 37.3 vs 35.0 ms, tea set 0.67 vs 0.57 ms, 1M triangles 9.64 vs 9.08 ms with four
+  // frames in flight) — waves whose calls all miss skip the fused shadow walk anyway.
+  bool shadow_pass = false;
   // Queue lengths of frames rendered with host read-backs: the same frame (camera, shard,
   // depth, mode) is then issued again without any synchronisation.
   struct WfPlan {
@@ -166,6 +176,7 @@ struct rt_scene {
     int depth = 0;
     bool fast = false;
     long long n[MAX_DEPTH + 1] = {}, front[MAX_DEPTH + 1] = {};
+    long long shadow[MAX_DEPTH + 1] = {};  // hits per level = entries of the level's shadow queue (-1: not known)
   };
   std::vector<WfPlan> wf_plans;  // most recent last, at most WF_MAX_PLANS
   // A wavefront frame is rendered as frame_split interleaved tile shards on streams of the
@@ -187,6 +198,12 @@ struct rt_scene {
   hipEvent_t split_fork = nullptr;
 };
 static constexpr size_t WF_MAX_PLANS = 64;
+// counters of one wavefront frame on the device: [2l], [2l+1] reflected / refracted rays queued for
+// level l; [WF_OVERFLOW_SLOT] a queue outgrew its estimate; [WF_SHADOW_SLOT0 + l] light loops
+// queued by level l
+constexpr int WF_OVERFLOW_SLOT = 2 * (MAX_DEPTH + 1);
+constexpr int WF_SHADOW_SLOT0 = 2 * (MAX_DEPTH + 2);
+constexpr int WF_N_COUNTS = WF_SHADOW_SLOT0 + MAX_DEPTH + 1;
 
 static bool affine_rows(const double* m16, double* out12, std::string& why) {
   if (!(m16[12] == 0.0 && m16[13] == 0.0 && m16[14] == 0.0 && m16[15] == 1.0)) {
@@ -468,6 +485,19 @@ struct alignas(16) WfNode {
   int32_t parent;  // previous-level node, or the output pixel index at level 0 (-1: no pixel)
   uint32_t flags;  // bit0: hit (otherwise the call returned black), bit1: Schlick mix, bit2: slot
 };
+// One shade_hit call's light loop (world.rs:43-52), queued by the level kernel for the shadow
+// pass: where the shadow rays start, what lighting() needs (light.rs:23-85), and where the
+// summed surface colour goes — into the call's result node when children will add to it, or,
+// with the rest of world.rs:57-64 evaluated on it, straight to the pixel / the parent's slot.
+struct alignas(16) WfShadow {
+  double over[3], normal[3], eyev[3], pc[3];
+  double coef, reflectance;
+  int32_t mat;
+  uint32_t node;   // index of the call in its level
+  int32_t parent;  // as WfNode::parent
+  uint32_t flags;  // WfNode::flags, bit3: the call has children (its node is stored)
+};
+static_assert(sizeof(WfShadow) == 128, "two cache lines per queued light loop");
 constexpr int WF_BLOCK = 64;
 
 #ifndef WF_WAVES
@@ -750,23 +780,24 @@ __device__ __forceinline__ long long wf_block_index() {
   return g * G + (r % 8) * (G / 8) + r / 8;
 }
 
-template <bool STATS, bool PRIMARY, bool FAST, bool COOP>
-__global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
-k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n, long long n_front,
-           unsigned int cap, WfNode* nodes, uint8_t* live, WfNode* parents, double* out_f64, uint8_t* out_u8,
-           WfTask* next,
-           unsigned int* next_count, unsigned int next_cap, int spawn, unsigned long long* counters,
-           const unsigned int* counts_in, unsigned int* overflow, SortGrid grid, const unsigned int* perm,
-           unsigned int* next_keys, unsigned int* hist) {
+// SHQ: the light loop of every hit is queued for k_wf_shadow instead of being run here.
+template <bool STATS, bool PRIMARY, bool FAST, bool COOP, bool SHQ>
+__device__ __forceinline__ void
+wf_level_body(const DScene& S, const DCamera& cam, const PixelMap& pm, const WfTask* tasks, long long n, long long n_front,
+              unsigned int cap, WfNode* nodes, uint8_t* live, WfNode* parents, double* out_f64, uint8_t* out_u8,
+              WfTask* next,
+              unsigned int* next_count, unsigned int next_cap, int spawn, unsigned long long* counters,
+              const unsigned int* counts_in, unsigned int* overflow, const SortGrid& grid, const unsigned int* perm,
+              unsigned int* next_keys, unsigned int* hist, WfShadow* shadow_q, unsigned int* shadow_count,
+              TravStack& st, const long long block) {
   static_assert(WF_BLOCK == 64, "the traversal stack is laid out for 64-lane blocks");
   static_assert(COOP || !FAST, "the f32 search exists on the shared leaf tests only");
-  RT_TRAV_STACK_COOP(st, S);
+  static_assert(COOP || !SHQ, "the shadow pass exists on the cooperative kernels only");
 #ifdef RT_SECTION_TIMES
   unsigned long long section_sum_[8] = {};
   unsigned long long section_t_ = __builtin_readcyclecounter();
 #endif
   Counters cnt{};
-  const long long block = wf_block_index();
   long long i = block * WF_BLOCK + threadIdx.x;
   bool active;
   Ray ray = {v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 1.0)};
@@ -868,29 +899,56 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
       finish_optics(S.mats[pr.mat_index], ray, pr, n1, n2, so);
       has_children = emit_result<STATS>(so, surface, nd, i, next, next_count, next_cap, spawn, cnt, grid, next_keys, hist);
     }
-    for (int li = 0; li < S.n_lights; li++) {
-      const DLight& L = S.lights[li];
-      Ray sr = {over, v3(0.0, 0.0, 1.0)};
-      double distance = 0.0;
-      C3 lit = {0.0, 0.0, 0.0}, dark = {0.0, 0.0, 0.0};
-      if (hit) {
-        shadow_ray(L, over, sr, distance);
-        if (STATS) cnt.rays_shadow++;
-        light_terms(S.mats[pr.mat_index], L, pc, sr.d, normal, eyev, lit, dark);
+    if (SHQ) {
+      // The light loop goes to the shadow pass: the hits of the wave take consecutive slots of
+      // the level's shadow queue (one atomic per wave), so that pass walks with full waves and
+      // nothing of this call waits, parked, for a shadow walk.
+      const unsigned long long hm = __ballot(hit);
+      if (hm != 0ull) {  // wave-uniform
+        const int lane = (int)__lane_id();
+        const int leader = __ffsll((long long)hm) - 1;
+        unsigned int base = 0;
+        if (lane == leader) base = atomicAdd(shadow_count, (unsigned int)__popcll(hm));
+        base = (unsigned int)__shfl((int)base, leader, 64);
+        if (hit) {
+          WfShadow& Q = shadow_q[base + (unsigned int)__popcll(hm & ((1ull << lane) - 1ull))];
+          Q.over[0] = over.x; Q.over[1] = over.y; Q.over[2] = over.z;
+          Q.normal[0] = normal.x; Q.normal[1] = normal.y; Q.normal[2] = normal.z;
+          Q.eyev[0] = eyev.x; Q.eyev[1] = eyev.y; Q.eyev[2] = eyev.z;
+          Q.pc[0] = pc.r; Q.pc[1] = pc.g; Q.pc[2] = pc.b;
+          Q.coef = nd.coef;
+          Q.reflectance = nd.reflectance;
+          Q.mat = pr.mat_index;
+          Q.node = (uint32_t)i;
+          Q.parent = nd.parent;
+          Q.flags = nd.flags | (has_children ? 8u : 0u);
+        }
       }
-      RT_SECTION(2);
-      const bool shadow = trace_any_coop<STATS, FAST>(S, sr, distance, hit, cnt, st);
-      RT_SECTION(3);
-      if (hit) {
-        surface.r += shadow ? dark.r : lit.r;
-        surface.g += shadow ? dark.g : lit.g;
-        surface.b += shadow ? dark.b : lit.b;
+    } else {
+      for (int li = 0; li < S.n_lights; li++) {
+        const DLight& L = S.lights[li];
+        Ray sr = {over, v3(0.0, 0.0, 1.0)};
+        double distance = 0.0;
+        C3 lit = {0.0, 0.0, 0.0}, dark = {0.0, 0.0, 0.0};
+        if (hit) {
+          shadow_ray(L, over, sr, distance);
+          if (STATS) cnt.rays_shadow++;
+          light_terms(S.mats[pr.mat_index], L, pc, sr.d, normal, eyev, lit, dark);
+        }
+        RT_SECTION(2);
+        const bool shadow = trace_any_coop<STATS, FAST>(S, sr, distance, hit, cnt, st);
+        RT_SECTION(3);
+        if (hit) {
+          surface.r += shadow ? dark.r : lit.r;
+          surface.g += shadow ? dark.g : lit.g;
+          surface.b += shadow ? dark.b : lit.b;
+        }
       }
-    }
-    if (hit) {
-      nd.surface[0] = surface.r;
-      nd.surface[1] = surface.g;
-      nd.surface[2] = surface.b;
+      if (hit) {
+        nd.surface[0] = surface.r;
+        nd.surface[1] = surface.g;
+        nd.surface[2] = surface.b;
+      }
     }
   } else {
     if (active) {
@@ -907,7 +965,7 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
   // k_wf_combine would evaluate on the stored node — and the way back up skips the node.
   if (has_children) {
     nodes[i] = nd;
-  } else if (PRIMARY || active) {
+  } else if ((PRIMARY || active) && !(SHQ && (nd.flags & 1u))) {  // (a queued hit is finished by k_wf_shadow)
     combine_node<PRIMARY>(nd, parents, out_f64, out_u8);
   }
   // one dense byte per call tells the level's combine pass which nodes to touch at all
@@ -932,6 +990,109 @@ __global__ void k_wf_combine(const WfNode* nodes, const uint8_t* live, long long
   combine_node<LEVEL0>(nodes[i], parents, out_f64, out_u8);
 }
 
+
+// The shadow pass of one level: one lane per queued light loop, full waves.  Per light, in the
+// scene's order (world.rs:43-52): the shadow ray of is_shadowed (world.rs:116-134), the any-hit
+// query, lighting() with its answer — the expressions and their order are those of the fused
+// kernel, so the surface colour is the same bits.  It then goes where the fused kernel would
+// have put it.  `block`: this wave's index within the pass.
+struct ShadowPass {
+  const WfShadow* q;
+  const unsigned int* count;  // left by the level kernel that queued the loops
+  WfNode* nodes;              // the level's result nodes
+  WfNode* parents;            // the nodes of the level above (null at level 0)
+  int level0;                 // the level above is the image
+};
+template <bool STATS, bool FAST>
+__device__ __forceinline__ void wf_shadow_body(const DScene& S, const ShadowPass& P, double* out_f64, uint8_t* out_u8,
+                                               unsigned long long* counters, TravStack& st, const long long block) {
+  Counters cnt{};
+  const WfShadow* q = P.q;
+  const long long n = *P.count;
+  if (block * WF_BLOCK >= n) return;  // wave-uniform
+  const long long i = block * WF_BLOCK + threadIdx.x;
+  const bool active = i < n;
+  // Only the shadow ray and the running sum live through a walk; what lighting() needs is read
+  // from the queue again when the walk is over (add_light with the query's answer evaluates the
+  // expressions light_terms evaluates both ways: the same bits).
+  C3 surface = {0.0, 0.0, 0.0};
+  for (int li = 0; li < S.n_lights; li++) {
+    const DLight& L = S.lights[li];
+    Ray sr = {v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 1.0)};
+    double distance = 0.0;
+    if (active) {
+      const WfShadow& Q = q[i];
+      shadow_ray(L, v3(Q.over[0], Q.over[1], Q.over[2]), sr, distance);
+      if (STATS) cnt.rays_shadow++;
+    }
+    const bool shadow = trace_any_coop<STATS, FAST>(S, sr, distance, active, cnt, st);
+    if (active) {
+      const WfShadow& Q = q[i];
+      const C3 pc = {Q.pc[0], Q.pc[1], Q.pc[2]};
+      add_light(S.mats[Q.mat], L, pc, sr.d, v3(Q.normal[0], Q.normal[1], Q.normal[2]),
+                v3(Q.eyev[0], Q.eyev[1], Q.eyev[2]), shadow, surface);
+    }
+  }
+  if (active) {
+    const WfShadow& Q = q[i];
+    if (Q.flags & 8u) {  // children will add to the node: only the surface colour is missing
+      WfNode& N = P.nodes[Q.node];
+      N.surface[0] = surface.r;
+      N.surface[1] = surface.g;
+      N.surface[2] = surface.b;
+    } else {  // the call's final value: shade_hit's last expression on a node without children
+      WfNode nd;
+      nd.surface[0] = surface.r;
+      nd.surface[1] = surface.g;
+      nd.surface[2] = surface.b;
+      for (int k = 0; k < 3; k++) {
+        nd.reflected[k] = 0.0;
+        nd.refracted[k] = 0.0;
+      }
+      nd.reflectance = Q.reflectance;
+      nd.coef = Q.coef;
+      nd.parent = Q.parent;
+      nd.flags = Q.flags;
+      if (P.level0)
+        combine_node<true>(nd, P.parents, out_f64, out_u8);
+      else
+        combine_node<false>(nd, P.parents, out_f64, out_u8);
+    }
+  }
+  flush_counters<STATS>(cnt, counters);
+}
+
+// One recursion level.  The launch's first `level_blocks` waves run the level's calls; with SHQ
+// the waves behind them run the shadow pass of the level BEFORE (its light loops were queued by
+// that level's launch), so the pass costs no launch of its own and its short, even walks fill
+// the end of this launch, where the level's longest walks would otherwise run alone.
+template <bool STATS, bool PRIMARY, bool FAST, bool COOP, bool SHQ>
+__global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
+k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n, long long n_front,
+           unsigned int cap, WfNode* nodes, uint8_t* live, WfNode* parents, double* out_f64, uint8_t* out_u8,
+           WfTask* next,
+           unsigned int* next_count, unsigned int next_cap, int spawn, unsigned long long* counters,
+           const unsigned int* counts_in, unsigned int* overflow, SortGrid grid, const unsigned int* perm,
+           unsigned int* next_keys, unsigned int* hist, WfShadow* shadow_q, unsigned int* shadow_count,
+           ShadowPass before, long long level_blocks) {
+  RT_TRAV_STACK_COOP(st, S);
+  const long long block = wf_block_index();
+  if (!SHQ || PRIMARY || block < level_blocks)
+    wf_level_body<STATS, PRIMARY, FAST, COOP, SHQ>(S, cam, pm, tasks, n, n_front, cap, nodes, live, parents, out_f64,
+                                                   out_u8, next, next_count, next_cap, spawn, counters, counts_in,
+                                                   overflow, grid, perm, next_keys, hist, shadow_q, shadow_count, st,
+                                                   block);
+  else
+    wf_shadow_body<STATS, FAST>(S, before, out_f64, out_u8, counters, st, block - level_blocks);
+}
+
+// The shadow pass of the last level of a frame (nothing follows that could carry it).
+template <bool STATS, bool FAST>
+__global__ void __launch_bounds__(WF_BLOCK, WF_WAVES)
+k_wf_shadow(DScene S, ShadowPass P, double* out_f64, uint8_t* out_u8, unsigned long long* counters) {
+  RT_TRAV_STACK_COOP(st, S);
+  wf_shadow_body<STATS, FAST>(S, P, out_f64, out_u8, counters, st, wf_block_index());
+}
 
 template <typename T>
 static int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
@@ -1001,6 +1162,7 @@ void rt_scene_destroy(rt_scene* s) {
         if (w->wf_tasks[l]) (void)hipFree(w->wf_tasks[l]);
         if (w->wf_nodes[l]) (void)hipFree(w->wf_nodes[l]);
         if (w->wf_live[l]) (void)hipFree(w->wf_live[l]);
+        if (w->wf_shadow[l]) (void)hipFree(w->wf_shadow[l]);
         if (w->wf_keys[l]) (void)hipFree(w->wf_keys[l]);
         if (w->wf_perm[l]) (void)hipFree(w->wf_perm[l]);
       }
@@ -1430,6 +1592,7 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
   if ((rc = upload(s, s->lights, &s->d.lights))) return rc;
   s->share_leaves = true;
   if (const char* e = getenv("RT_SHARE_LEAVES")) s->share_leaves = atoi(e) != 0;
+  if (const char* e = getenv("RT_SHADOW_PASS")) s->shadow_pass = atoi(e) != 0;
   if (const char* e = getenv("RT_FRAME_SPLIT")) s->frame_split = std::min(std::max(atoi(e), 0), 8);
   s->d.n_groups = (int32_t)groups.size();
   s->d.n_prims = (int32_t)prims.size();
@@ -1552,12 +1715,14 @@ static void resolve_estimate(rt_scene* s, rt_scene::WfState* w, int* complete) {
   plan.fast = w->estimate_fast;
   plan.n[0] = plan.front[0] = w->estimate_n0;
   plan.levels = 1;
+  for (int l = 0; l <= MAX_DEPTH; l++) plan.shadow[l] = -1;
   for (int l = 1; l < w->estimate_depth; l++) {
     plan.front[l] = h[2 * l];
     plan.n[l] = (long long)h[2 * l] + (long long)h[2 * l + 1];
     if (plan.n[l] == 0) break;
     plan.levels = l + 1;
   }
+  for (int l = 0; l < plan.levels; l++) plan.shadow[l] = h[WF_SHADOW_SLOT0 + l];
   for (size_t i = 0; i < s->wf_plans.size(); i++)
     if (s->wf_plans[i].key == plan.key && same_frame(s->wf_plans[i].id, plan.id)) {
       s->wf_plans.erase(s->wf_plans.begin() + (long)i);
@@ -1597,7 +1762,7 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
   // and buffers are sized from that frame's queue lengths plus a margin, the kernels take the
   // true lengths from the device, and a level that outgrows its estimate marks the frame as
   // incomplete (rt_estimated_frame_result tells; the caller renders it again the exact way).
-  constexpr int OVERFLOW_SLOT = 2 * (MAX_DEPTH + 1);
+  constexpr int OVERFLOW_SLOT = WF_OVERFLOW_SLOT;
   const rt_scene::WfPlan* estimate = nullptr;
   if (!planned && s->allow_estimates && !stats)
     for (const rt_scene::WfPlan& c : s->wf_plans)
@@ -1643,10 +1808,10 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
   w->last_use = ++s->wf_tick;
   w->estimate_pending = false;  // a new frame on this stream: an unasked verdict of an earlier one is void
   if (!w->wf_counts) {
-    HIP_TRY(hipMalloc(&w->wf_counts, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int)));
-    HIP_TRY(hipHostMalloc(&w->wf_counts_host, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(&w->wf_counts, WF_N_COUNTS * sizeof(unsigned int)));
+    HIP_TRY(hipHostMalloc(&w->wf_counts_host, WF_N_COUNTS * sizeof(unsigned int)));
   }
-  HIP_TRY(hipMemsetAsync(w->wf_counts, 0, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int), st));
+  HIP_TRY(hipMemsetAsync(w->wf_counts, 0, WF_N_COUNTS * sizeof(unsigned int), st));
   long long n = ntiles * (RT_TILE * RT_TILE);
   long long n_front = n;     // level 0 has no queue
   unsigned int cap_in = 0;
@@ -1659,6 +1824,8 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     bool spawn = (l + 1 < depth);
     if ((rc = wf_ensure(&w->wf_nodes[l], &w->wf_node_cap[l], (size_t)n, sizeof(WfNode)))) return rc;
     if ((rc = wf_ensure(&w->wf_live[l], &w->wf_live_cap[l], (size_t)n, 1))) return rc;
+    const bool shq = s->shadow_pass && (fast || s->share_leaves);
+    if (shq && (rc = wf_ensure(&w->wf_shadow[l], &w->wf_shadow_cap[l], (size_t)n, sizeof(WfShadow)))) return rc;
     if (spawn) {
       if (2 * n > 0xfffffff0LL) return fail(RT_ERR_UNSUPPORTED, "ray queue exceeds 2^32 entries");
       if ((rc = wf_ensure(&w->wf_tasks[l + 1], &w->wf_task_cap[l + 1], (size_t)(2 * n), sizeof(WfTask))))
@@ -1682,7 +1849,23 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     sgrid.enabled = sort_next ? 1 : 0;
     const unsigned int* perm_in = sorted_in ? static_cast<const unsigned int*>(w->wf_perm[l]) : nullptr;
     unsigned int* keys_next = sort_next ? static_cast<unsigned int*>(w->wf_keys[l + 1]) : nullptr;
-    dim3 grid((unsigned)((n + WF_BLOCK - 1) / WF_BLOCK)), block(WF_BLOCK);
+    // With the shadow pass, this launch also carries the light loops the level before has queued
+    // (behind the level's own waves): as many waves as that level had hits when the count is
+    // known (a planned frame), as many as it had calls otherwise; the kernel reads the true count.
+    const long long level_blocks = (n + WF_BLOCK - 1) / WF_BLOCK;
+    ShadowPass before{};
+    long long before_blocks = 0;
+    if (shq && l > 0) {
+      const long long ns = (planned && plan.shadow[l - 1] >= 0) ? plan.shadow[l - 1] : level_n[l - 1];
+      before_blocks = (ns + WF_BLOCK - 1) / WF_BLOCK;
+      before.q = static_cast<const WfShadow*>(w->wf_shadow[l - 1]);
+      before.count = w->wf_counts + WF_SHADOW_SLOT0 + (l - 1);
+      before.nodes = static_cast<WfNode*>(w->wf_nodes[l - 1]);
+      before.parents = (l > 1) ? static_cast<WfNode*>(w->wf_nodes[l - 2]) : nullptr;
+      before.level0 = (l == 1) ? 1 : 0;
+    }
+    if (level_blocks + before_blocks > 0x7fffffffLL) return fail(RT_ERR_UNSUPPORTED, "too many waves in one launch");
+    dim3 grid((unsigned)(level_blocks + before_blocks)), block(WF_BLOCK);
     const WfTask* tin = static_cast<const WfTask*>(w->wf_tasks[l]);
     WfNode* nodes = static_cast<WfNode*>(w->wf_nodes[l]);
     WfTask* tnext = spawn ? static_cast<WfTask*>(w->wf_tasks[l + 1]) : nullptr;
@@ -1692,20 +1875,26 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     // spawns nothing needs no pass of its own on the way up
     WfNode* parents = (l > 0) ? static_cast<WfNode*>(w->wf_nodes[l - 1]) : nullptr;
     spawned[l] = spawn;
-#define WF_LAUNCH(ST, PR, FA, CO)                                                                        \
-  hipLaunchKernelGGL((k_wf_level<ST, PR, FA, CO>), grid, block, 0, st, s->d, dc, pm, tin, n, n_front, cap_in, \
+#define WF_LAUNCH(ST, PR, FA, CO, SQ)                                                                    \
+  hipLaunchKernelGGL((k_wf_level<ST, PR, FA, CO, SQ>), grid, block, 0, st, s->d, dc, pm, tin, n, n_front, cap_in, \
                      nodes, static_cast<uint8_t*>(w->wf_live[l]), parents, d_f64, d_u8, tnext, cnt_next, cap,   \
                      spawn ? 1 : 0, s->d_counters,                                                              \
                      (estimate && l > 0) ? w->wf_counts + 2 * l : (const unsigned int*)nullptr,                \
-                     w->wf_counts + OVERFLOW_SLOT, sgrid, perm_in, keys_next, w->wf_hist)
-#define WF_LAUNCH2(ST, PR)              \
-  do {                                  \
-    if (fast)                           \
-      WF_LAUNCH(ST, PR, true, true);    \
-    else if (s->share_leaves)           \
-      WF_LAUNCH(ST, PR, false, true);   \
-    else                                \
-      WF_LAUNCH(ST, PR, false, false);  \
+                     w->wf_counts + OVERFLOW_SLOT, sgrid, perm_in, keys_next, w->wf_hist,                       \
+                     static_cast<WfShadow*>(w->wf_shadow[l]), w->wf_counts + WF_SHADOW_SLOT0 + l, before,      \
+                     level_blocks)
+#define WF_LAUNCH2(ST, PR)                    \
+  do {                                        \
+    if (fast && shq)                          \
+      WF_LAUNCH(ST, PR, true, true, true);    \
+    else if (fast)                            \
+      WF_LAUNCH(ST, PR, true, true, false);   \
+    else if (s->share_leaves && shq)          \
+      WF_LAUNCH(ST, PR, false, true, true);   \
+    else if (s->share_leaves)                 \
+      WF_LAUNCH(ST, PR, false, true, false);  \
+    else                                      \
+      WF_LAUNCH(ST, PR, false, false, false); \
   } while (0)
     if (l == 0) {
       if (stats) WF_LAUNCH2(true, true); else WF_LAUNCH2(false, true);
@@ -1718,6 +1907,12 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     s->launches++;
     level_n[l] = n;
     levels = l + 1;
+    if (!planned && !estimate) {
+      // the level's hit count, for the plan (it travels with the queue lengths read below, or,
+      // for the last level, is waited for after the loop)
+      HIP_TRY(hipMemcpyAsync(w->wf_counts_host + WF_SHADOW_SLOT0 + l, w->wf_counts + WF_SHADOW_SLOT0 + l,
+                             sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    }
     if (!spawn) break;
     if (planned) {
       if (l + 1 >= plan.levels) break;
@@ -1758,9 +1953,33 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     }
     if (n == 0 && !estimate) break;
   }
+  if (levels > 0 && s->shadow_pass && (fast || s->share_leaves)) {
+    // the light loops of the last level: nothing follows that could carry them
+    const int l = levels - 1;
+    const long long ns = (planned && plan.shadow[l] >= 0) ? plan.shadow[l] : level_n[l];
+    if (ns > 0) {
+      ShadowPass last{};
+      last.q = static_cast<const WfShadow*>(w->wf_shadow[l]);
+      last.count = w->wf_counts + WF_SHADOW_SLOT0 + l;
+      last.nodes = static_cast<WfNode*>(w->wf_nodes[l]);
+      last.parents = (l > 0) ? static_cast<WfNode*>(w->wf_nodes[l - 1]) : nullptr;
+      last.level0 = (l == 0) ? 1 : 0;
+      dim3 sgrid_dim((unsigned)((ns + WF_BLOCK - 1) / WF_BLOCK)), block(WF_BLOCK);
+#define WF_SHADOW(ST, FA) \
+  hipLaunchKernelGGL((k_wf_shadow<ST, FA>), sgrid_dim, block, 0, st, s->d, last, d_f64, d_u8, s->d_counters)
+      if (stats) {
+        if (fast) WF_SHADOW(true, true); else WF_SHADOW(true, false);
+      } else {
+        if (fast) WF_SHADOW(false, true); else WF_SHADOW(false, false);
+      }
+#undef WF_SHADOW
+      HIP_TRY(hipGetLastError());
+      s->launches++;
+    }
+  }
   if (estimate) {
     // the true queue lengths follow the frame to the host; rt_estimated_frame_result reads them
-    HIP_TRY(hipMemcpyAsync(w->wf_counts_host, w->wf_counts, 2 * (MAX_DEPTH + 2) * sizeof(unsigned int),
+    HIP_TRY(hipMemcpyAsync(w->wf_counts_host, w->wf_counts, WF_N_COUNTS * sizeof(unsigned int),
                            hipMemcpyDeviceToHost, st));
     w->estimate_pending = true;
     s->n_estimated++;
@@ -1771,6 +1990,9 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     w->estimate_fast = fast;
   } else if (!planned) {
     plan.levels = levels;
+    HIP_TRY(hipStreamSynchronize(st));  // the last level's hit count
+    for (int l = 0; l <= MAX_DEPTH; l++)
+      plan.shadow[l] = (l < levels && s->shadow_pass) ? (long long)w->wf_counts_host[WF_SHADOW_SLOT0 + l] : -1;
     if (s->wf_plans.size() >= WF_MAX_PLANS) s->wf_plans.erase(s->wf_plans.begin());
     s->wf_plans.push_back(plan);
     if (getenv("RT_TRACE_LEVELS"))  // queue length of every level of a newly planned frame
@@ -2021,10 +2243,11 @@ int rt_render_device_noalloc(rt_scene* s, const rt_camera* cam, int depth, int m
       const unsigned int cap = spawn ? (unsigned int)(2 * n) : 0u;
       const unsigned int* counts_in = l > 0 ? counts + 2 * l : nullptr;
 #define NA_LAUNCH(PR, FA)                                                                                   \
-  hipLaunchKernelGGL((k_wf_level<false, PR, FA, true>), grid, block, 0, st, s->d, dc, pm, tin, n, n, cap_in, \
+  hipLaunchKernelGGL((k_wf_level<false, PR, FA, true, false>), grid, block, 0, st, s->d, dc, pm, tin, n, n, cap_in, \
                      nodes, live, parents, d_rgb_f64, d_rgb_u8, tnext, counts + 2 * (l + 1), cap,            \
                      spawn ? 1 : 0, s->d_counters, counts_in, counts + OVERFLOW_SLOT, SortGrid{}, (const unsigned int*)nullptr, \
-                     (unsigned int*)nullptr, (unsigned int*)nullptr)
+                     (unsigned int*)nullptr, (unsigned int*)nullptr, (WfShadow*)nullptr, (unsigned int*)nullptr,     \
+                     ShadowPass{}, (long long)grid.x)
       if (l == 0) {
         if (fast) NA_LAUNCH(true, true); else NA_LAUNCH(true, false);
       } else {
