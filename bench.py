@@ -126,15 +126,46 @@ def cpu_baseline(example, hs, vs, ntris, pixels, target_s=7.0):
 
 def measured_traffic(workload, pipeline):
     """HBM bytes per frame of the render kernels from the committed rocprofv3 PMC passes of
-    this same command (FETCH_SIZE doubled as gfx950 requires, plus WRITE_SIZE), or None."""
-    for rnd in ("r02", "r01"):
+    this same command (FETCH_SIZE doubled as gfx950 requires, plus WRITE_SIZE), the per-frame
+    sums of the other counters of those passes (or {}), and the file's name; (None, {}, None)
+    without a committed profile."""
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(REPO, "profiles", f"{rnd}_{pipeline}_{workload}_pmc.json")
         try:
             with open(path) as f:
-                return float(json.load(f)["render_kernels_per_frame"]["hbm_bytes"]), os.path.basename(path)
+                per_frame = json.load(f)["render_kernels_per_frame"]
+            return float(per_frame["hbm_bytes"]), per_frame.get("counters", {}), os.path.basename(path)
         except (OSError, KeyError, ValueError):
             continue
-    return None, None
+    return None, {}, None
+
+
+SIMDS = 1024          # 256 CUs x 4
+PEAK_CLOCK_HZ = 2.4e9  # MI355X peak engine clock
+
+
+def pmc_derived(c, kernel_ms):
+    """Utilisation figures from the committed PMC passes (per-frame counter sums `c`) and the
+    frame time measured live.  SQ_INSTS_VALU counts wave instructions, each of which holds a SIMD's
+    vector unit for 4 cycles: valu_issue_util = SQ_INSTS_VALU x 4 / (1024 SIMDs x clock x time).
+    SQ_WAVE_CYCLES / SQ_WAIT_ANY count quad-cycles per resident wave.  The clock is the peak
+    engine clock (the chip runs below it under load, so the true utilisation is a little higher)."""
+    if not c:
+        return None
+    slots = SIMDS * PEAK_CLOCK_HZ * kernel_ms * 1e-3  # SIMD cycles in one frame's time
+    out = {"source": "committed PMC passes (profiles/), per frame; time = this run's kernel_ms"}
+    if "SQ_INSTS_VALU" in c:
+        out["valu_insts_per_frame"] = c["SQ_INSTS_VALU"]
+        out["valu_issue_util"] = c["SQ_INSTS_VALU"] * 4 / slots
+    if "SQ_INSTS_SALU" in c:
+        out["salu_insts_per_frame"] = c["SQ_INSTS_SALU"]
+    if "SQ_WAVE_CYCLES" in c:
+        out["waves_per_simd"] = c["SQ_WAVE_CYCLES"] * 4 / slots
+        if "SQ_WAIT_ANY" in c:
+            out["wave_wait_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
+        out["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    return out
 
 
 def main():
@@ -157,8 +188,9 @@ def main():
                          "-1 = 8 on one GPU, 12 per rank on several (the exchange has a stream of its own)")
     ap.add_argument("--bvh", default="auto", choices=["sah", "lbvh", "auto"],
                     help="host binned-SAH build, device LBVH build, or by mesh size (device from 100k triangles on)")
-    ap.add_argument("--sustain-s", type=float, default=1.0,
-                    help="after the timed steps, the same loop again for at least this long (0 = skip)")
+    ap.add_argument("--sustain-s", type=float, default=6.0,
+                    help="after the timed steps, the same loop again for at least this long (0 = skip); long "
+                         "enough by default for a coarse GPU-activity sampler to land inside it")
     ap.add_argument("--cpu-pixels", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -238,8 +270,11 @@ def main():
         if rank == 0:
             rt.detile_u8(all_tiles[slot].data_ptr(), n, per, hs, vs, images[slot].data_ptr(), stream)
 
+    frames_issued = [0]
+
     def step(k=0, want_stats=False):
         """Frame k: rendered (and, for n > 1, exchanged) on stream k % F with that slot's buffers."""
+        frames_issued[0] += 1
         slot = k % F
         with torch.cuda.stream(streams[slot]):
             stream = streams[slot].cuda_stream
@@ -256,7 +291,8 @@ def main():
     torch.cuda.synchronize()
     st = w.stats().as_dict()
     keys = ["rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "depth0_skipped", "pred_queries",
-            "nodes_visited", "tri_tests", "prim_tests", "inst_entries", "shade_calls"]
+            "nodes_visited", "tri_tests", "prim_tests", "inst_entries", "shade_calls", "node_wave_steps",
+            "tri_wave_steps"]
     if n > 1:
         t = all_reduce(torch.tensor([st[k] for k in keys], dtype=torch.int64, device=dev))
         st.update({k: int(v) for k, v in zip(keys, t.tolist())})
@@ -320,7 +356,17 @@ def main():
         # per launch: this rank's share of the frame (1/n of the counters for n > 1)
         ach_gbs = abytes / n / (kernel_ms * 1e-3) / 1e9
         ach_tf = aflops / n / (kernel_ms * 1e-3) / 1e12
-        traffic, traffic_src = measured_traffic(args.workload, args.pipeline) if n == 1 else (None, None)
+        traffic, pmc, traffic_src = measured_traffic(args.workload, args.pipeline) if n == 1 else (None, {}, None)
+        # what the frame has to move whatever the kernels do: the scene once, the image, every
+        # queued ray written and read once (64 B), every shaded call's result node written and
+        # read once (96 B) and its flag byte
+        npx = hs * vs
+        traffic_needed = (info["device_bytes"] + 3 * npx + 128 * (st["rays_reflect"] + st["rays_refract"]) +
+                          194 * st["shade_calls"]) / n
+        lanes = {"node_lanes_per_step": st["nodes_visited"] / max(1, st["node_wave_steps"]),
+                 "tri_lanes_per_step": st["tri_tests"] / max(1, st["tri_wave_steps"]),
+                 "note": "of 64; from the STATS counters of one frame (visits / wave iterations)"}
+        util = pmc_derived(pmc, kernel_ms)
         kernel = ("k_render_mega" if args.pipeline == "megakernel" else
                   "k_wf_level (one launch per recursion level; the frame's launches taken together)")
         # Which roof binds: the example scenes (a few MB) are served from L2 / Infinity Cache, so
@@ -330,7 +376,10 @@ def main():
         valu = {"bound": "valu_f64", "achieved": ach_tf, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach_tf / PEAK_F64_TFLOPS,
                 "peak_no_fma": PEAK_F64_NO_FMA_TFLOPS, "frac_no_fma": ach_tf / PEAK_F64_NO_FMA_TFLOPS,
-                "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": kernel_ms,
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_needed": traffic_needed,
+                "traffic_ratio": None if traffic is None else traffic / traffic_needed,
+                "utilisation": util, "lanes": lanes,
+                "kernel": kernel, "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": aflops / n,
                 "single_frame_frac": (aflops / n / (frame_latency_ms * 1e-3) / 1e12) / PEAK_F64_TFLOPS,
                 "note": "flops = 18 per child box test (4 per node) + 46 per triangle test + 56 per ray-into-group "
@@ -340,7 +389,10 @@ def main():
         hbm_measured = None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9
         hbm = {"bound": "hbm", "achieved": hbm_measured, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                "frac": None if hbm_measured is None else hbm_measured / PEAK_HBM_GBS,
-               "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": kernel_ms,
+               "traffic": traffic, "traffic_source": traffic_src, "traffic_needed": traffic_needed,
+               "traffic_ratio": None if traffic is None else traffic / traffic_needed,
+               "utilisation": util, "lanes": lanes,
+               "kernel": kernel, "kernel_ms": kernel_ms,
                "algorithmic_bytes_per_launch": abytes / n,
                "algorithmic_GBps": ach_gbs,
                "note": "achieved = measured HBM bytes per frame (rocprofv3 FETCH_SIZE x2 as gfx950 requires + WRITE_SIZE, "
@@ -354,7 +406,10 @@ def main():
             "value": value, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64" if args.mode == "f64_parity" else "f32 triangle search + f64 shading", "data": "synthetic",
+            "dtype": "f64" if args.mode == "f64_parity" else "f32 triangle search + f64 shading",
+            "data": ("synthetic (seeded generator, 1M triangles)" if ntris else
+                     "the reference's own example scene (examples.rs; OBJ assets of the reference repository under "
+                     "assets/obj), camera size as the benchmark config states; no external dataset"),
             "config": {"workload": desc, "hsize": hs, "vsize": vs, "depth": 5, "mode": args.mode,
                        "pipeline": args.pipeline, "frames_in_flight": F, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "frame_latency_ms": frame_latency_ms, "bvh": args.bvh, "commit_ms": info["commit_ms"], "rays_per_frame": rays_per_frame,
                        "parallelism": f"tiles{rt.TILE}x{rt.TILE} round-robin over {n} GPU(s)" + (", RCCL gather to rank 0" if n > 1 else ""),
@@ -369,6 +424,7 @@ def main():
             "roofline": hbm if hbm_bound else valu,
             ("roofline_valu_f64" if hbm_bound else "roofline_hbm"): valu if hbm_bound else hbm,
             "counters_per_frame": {k: st[k] for k in keys},
+            "frames_issued": frames_issued[0],  # by this process, all told (a profile of the run divides by it)
         }
         if args.mode == "f32_fast" and n == 1:
             # the fast mode is reported with its pixel-match rate against the parity mode's frame

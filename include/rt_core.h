@@ -52,8 +52,12 @@ enum {
 enum { RT_SPHERE = 0, RT_PLANE = 1, RT_CUBE = 2, RT_CYLINDER = 3, RT_CONE = 4 };
 /* draw/patterns.rs:29-306 */
 enum { RT_SOLID = 0, RT_STRIPE = 1, RT_GRADIENT = 2, RT_RINGS = 3, RT_CHECKERED = 4 };
-/* arithmetic mode of the kernels */
-enum { RT_MODE_F64_PARITY = 0, RT_MODE_F32_FAST = 1 };
+/* Arithmetic mode of the kernels.  RT_MODE_F32_SEARCH (historic name RT_MODE_F32_FAST): the
+ * triangle search runs in f32 with error bounds and everything it cannot decide, and all
+ * shading, in f64; it renders the parity mode's frames bit for bit and is NOT faster on CDNA4
+ * (non-packed f32 and f64 vector instructions issue at the same rate there, and the bounds double
+ * the test's instructions): about 20 % slower than RT_MODE_F64_PARITY.  Kept for its counters. */
+enum { RT_MODE_F64_PARITY = 0, RT_MODE_F32_FAST = 1, RT_MODE_F32_SEARCH = 1 };
 /* kernel organisation: one lane per pixel with an explicit recursion stack, or per-depth
  * ray queues with one fused trace+shade kernel per depth ("wavefront") */
 enum { RT_PIPELINE_MEGAKERNEL = 0, RT_PIPELINE_WAVEFRONT = 1,

@@ -18,6 +18,8 @@ pub const RT_RINGS: i32 = 3;
 pub const RT_CHECKERED: i32 = 4;
 pub const RT_MODE_F64_PARITY: c_int = 0;
 pub const RT_MODE_F32_FAST: c_int = 1;
+/// The same mode under the name that says what it is: the f32-search variant (not faster on CDNA4).
+pub const RT_MODE_F32_SEARCH: c_int = 1;
 pub const RT_PIPELINE_MEGAKERNEL: c_int = 0;
 pub const RT_PIPELINE_WAVEFRONT: c_int = 1;
 pub const RT_PIPELINE_AUTO: c_int = 2;

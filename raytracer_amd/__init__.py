@@ -22,6 +22,7 @@ SPHERE, PLANE, CUBE, CYLINDER, CONE = range(5)
 GROUP = 7
 SOLID, STRIPE, GRADIENT, RINGS, CHECKERED = range(5)
 MODE_F64_PARITY, MODE_F32_FAST = 0, 1
+MODE_F32_SEARCH = MODE_F32_FAST  # what it is: the f32-search variant (same frames, not faster on CDNA4)
 PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT, PIPELINE_AUTO = 0, 1, 2
 # pipeline used when a render call does not name one
 DEFAULT_PIPELINE = PIPELINE_WAVEFRONT

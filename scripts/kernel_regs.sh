@@ -3,7 +3,7 @@
 # (the code object's metadata notes): scripts/kernel_regs.sh [pattern]
 set -e
 cd "$(dirname "$0")/.."
-OBJ=raytracer_amd/build/rt_core.o
+OBJ=${OBJ:-raytracer_amd/build/rt_core.o}
 TMP=$(mktemp -d)
 /opt/rocm/lib/llvm/bin/llvm-objcopy --dump-section .hip_fatbin=$TMP/fat.bin $OBJ
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$TMP/fat.bin --output=$TMP/k.co

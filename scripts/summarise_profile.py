@@ -2,7 +2,8 @@
   <out>_kernel_stats.csv  rocprofv3 --kernel-trace --stats summary, verbatim
   <out>_pmc.json          per-kernel means of every PMC pass + per-frame HBM traffic
   <out>_bench.json        the bench line printed under the stats pass
-usage: python scripts/summarise_profile.py <tag> <out-prefix> <frames-per-run>"""
+usage: python scripts/summarise_profile.py <tag> <out-prefix> [frames-per-run]
+(frames per run: taken from the bench line's "frames_issued" when not given)"""
 import collections
 import csv
 import glob
@@ -10,8 +11,9 @@ import json
 import shutil
 import sys
 
-tag, out, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
+tag, out = sys.argv[1], sys.argv[2]
 root = f"gpurun_out/prof_{tag}"
+frames = int(sys.argv[3]) if len(sys.argv) > 3 else int(json.load(open(f"{root}/stats_bench.json"))["frames_issued"])
 shutil.copy(glob.glob(f"{root}/stats/*/*kernel_stats.csv")[0], f"{out}_kernel_stats.csv")
 shutil.copy(f"{root}/stats_bench.json", f"{out}_bench.json")
 per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -21,11 +23,15 @@ for f in glob.glob(f"{root}/pmc_*/*/*_counter_collection.csv"):
         per_kernel[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {}
 fetch_kb = write_kb = 0.0
+sq = collections.defaultdict(float)  # SQ / TCC / GRBM counters summed over the render kernels' launches
 for k, cs in sorted(per_kernel.items()):
     summary[k] = {c: {"launches": len(v), "mean_per_launch": sum(v) / len(v), "sum": sum(v)} for c, v in sorted(cs.items())}
     if k.startswith(("void k_wf", "void k_render", "k_wf", "k_render")):
         fetch_kb += sum(cs.get("FETCH_SIZE", []))
         write_kb += sum(cs.get("WRITE_SIZE", []))
+        for c, v in cs.items():
+            if c.startswith(("SQ_", "TCC_", "TCP_", "GRBM_")):
+                sq[c] += sum(v)
 doc = {
     "command": "rocprofv3 --pmc <one pass per group> -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline",
     "frames_per_run": frames,
@@ -35,6 +41,9 @@ doc = {
         "fetch_bytes_corrected": 2 * 1024 * fetch_kb / frames,
         "write_bytes": 1024 * write_kb / frames,
         "hbm_bytes": (2 * 1024 * fetch_kb + 1024 * write_kb) / frames,
+        # wave-level instruction counts; SQ_WAVE_CYCLES / SQ_WAIT_ANY / SQ_ACTIVE_INST_* count
+        # quad-cycles (x4 = shader cycles); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        "counters": {c: v / frames for c, v in sorted(sq.items())},
     },
     "kernels": summary,
 }
