@@ -290,13 +290,13 @@ class World:
             self._err("get_camera")
         return cam
 
-    def commit(self, device=-1, bvh_builder=2):
+    def commit(self, device=-1, bvh_builder=1):
         if self.L.rth_commit(self.h, device, bvh_builder) != 0:
             self._err("commit")
         self.committed = True
         return self
 
-    def commit_multi(self, devices, bvh_builder=2):
+    def commit_multi(self, devices, bvh_builder=1):
         """rt_scene_commit_multi: the scene on several GPUs; render() then uses all of them."""
         devs = (C.c_int * len(devices))(*devices)
         if self.L.rth_commit_multi(self.h, devs, len(devices), bvh_builder) != 0:

@@ -187,14 +187,15 @@ __global__ void k_radix_tree(const unsigned long long* keys, int n, int* child_l
 // inner right child by the first of its, which no two nodes of one subtree can share.
 constexpr int TREELET = 64;
 
+// the maximal subtrees of at least `least` and at most `most` triangles
 __global__ void k_find_treelets(const int* range_first, const int* range_last, const int* parent_inner,
-                                int n_inner, int* list, int* n_list) {
+                                int n_inner, int least, int most, int* list, int* n_list) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_inner) return;
   const int count = range_last[i] - range_first[i] + 1;
-  if (count > TREELET || count < 3) return;  // two triangles can be split one way only
+  if (count > most || count < least) return;
   const int p = parent_inner[i];
-  if (p >= 0 && range_last[p] - range_first[p] + 1 <= TREELET) return;  // part of a larger one
+  if (p >= 0 && range_last[p] - range_first[p] + 1 <= most) return;  // part of a larger one
   list[atomicAdd(n_list, 1)] = i;
 }
 
@@ -317,6 +318,237 @@ k_rebuild_treelets(const int* list, int n_list, uint32_t* faces, const Box6* tri
     __syncthreads();
   }
   if (lane < m) faces[F + lane] = face;
+}
+
+
+// ---- surface-area rebuild of the large subtrees ---------------------------------------------------
+// Above the 64-triangle subtrees the radix tree's median splits still cost a few per cent of
+// frame time on meshes of a few ten thousand triangles (the pawn).  Every maximal subtree of at
+// most BIG_TREELET triangles is therefore split again from its root down by the binned
+// surface-area heuristic (16 bins per axis on the centroids, the host builder's rule for large
+// ranges), one workgroup per subtree with the subtree's slice of the order array in LDS, until
+// the ranges have at most TREELET triangles: those are left, as ranges with a root and nothing
+// below it, to k_rebuild_treelets.  Node numbering as there: an inner left child takes the last
+// position of its range, an inner right child the first of its.  The inner nodes the radix tree
+// had inside the subtree are marked empty first (a range of one position), so that no stale
+// node is ever taken for a subtree's root.
+constexpr int BIG_TREELET = 8192;
+constexpr int BIG_THREADS = 1024;
+constexpr int BIG_BINS = 16;
+
+__device__ inline unsigned f32_ordered(float x) {  // order-preserving image, for integer min / max
+  const unsigned b = __float_as_uint(x);
+  return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+__device__ inline float f32_from_ordered(unsigned e) {
+  return __uint_as_float((e >> 31) ? (e & 0x7fffffffu) : ~e);
+}
+
+__global__ void __launch_bounds__(BIG_THREADS)
+k_rebuild_big_treelets(const int* list, int n_list, uint32_t* faces, const Box6* tri_boxes, int* child_l, int* child_r,
+                       int* range_first, int* range_last, int* parent_inner, int* parent_leaf, int n_inner) {
+  if ((int)blockIdx.x >= n_list) return;
+  const int root = list[blockIdx.x];
+  const int F = range_first[root], m = range_last[root] - F + 1;  // TREELET < m <= BIG_TREELET
+  const int tid = threadIdx.x;
+  __shared__ uint32_t s_face[BIG_TREELET], s_tmp[BIG_TREELET];
+  __shared__ unsigned short s_bin[BIG_TREELET];  // the three axes' bins of a triangle, 4 bits each
+  __shared__ unsigned s_cmin[3], s_cmax[3];
+  __shared__ unsigned s_blo[3][BIG_BINS][3], s_bhi[3][BIG_BINS][3];
+  __shared__ int s_bcount[3][BIG_BINS];
+  __shared__ float s_cost[3 * BIG_BINS];
+  __shared__ int s_scan[BIG_THREADS];
+  __shared__ int todo_first[128], todo_last[128], todo_node[128];
+  __shared__ int s_sp, s_axis, s_split;
+  for (int j = tid; j < m; j += BIG_THREADS) s_face[j] = faces[F + j];
+  for (int j = F + 1 + tid; j <= F + m - 2; j += BIG_THREADS)  // the radix tree's nodes inside: empty
+    if (j < n_inner && j != root) {
+      range_first[j] = j;
+      range_last[j] = j;
+    }
+  if (tid == 0) {
+    todo_first[0] = 0;
+    todo_last[0] = m - 1;
+    todo_node[0] = root;
+    s_sp = 1;
+  }
+  __syncthreads();
+  const float inf = __builtin_huge_valf();
+  while (true) {
+    __syncthreads();
+    const int sp = s_sp;
+    if (sp == 0) break;
+    const int f = todo_first[sp - 1], l = todo_last[sp - 1], node = todo_node[sp - 1];
+    const int count = l - f + 1;
+    __syncthreads();
+    // centroid bounds of the range
+    if (tid < 3) {
+      s_cmin[tid] = 0xffffffffu;
+      s_cmax[tid] = 0u;
+    }
+    for (int k = tid; k < 3 * BIG_BINS * 3; k += BIG_THREADS) {
+      (&s_blo[0][0][0])[k] = 0xffffffffu;
+      (&s_bhi[0][0][0])[k] = 0u;
+    }
+    for (int k = tid; k < 3 * BIG_BINS; k += BIG_THREADS) (&s_bcount[0][0])[k] = 0;
+    __syncthreads();
+    for (int j = f + tid; j <= l; j += BIG_THREADS) {
+      const Box6 b = tri_boxes[s_face[j]];
+      for (int a = 0; a < 3; a++) {
+        const unsigned c = f32_ordered((float)(b.lo[a] + b.hi[a]));
+        atomicMin(&s_cmin[a], c);
+        atomicMax(&s_cmax[a], c);
+      }
+    }
+    __syncthreads();
+    float cmin[3], scale[3];
+    for (int a = 0; a < 3; a++) {
+      cmin[a] = f32_from_ordered(s_cmin[a]);
+      const float ext = f32_from_ordered(s_cmax[a]) - cmin[a];
+      scale[a] = (ext > 0.0f && ext < inf) ? (float)BIG_BINS / ext : 0.0f;
+    }
+    // bins: box and count per (axis, bin)
+    for (int j = f + tid; j <= l; j += BIG_THREADS) {
+      const Box6 b = tri_boxes[s_face[j]];
+      unsigned packed = 0;
+      for (int a = 0; a < 3; a++) {
+        const float c = (float)(b.lo[a] + b.hi[a]);
+        int bin = (int)((c - cmin[a]) * scale[a]);
+        bin = min(max(bin, 0), BIG_BINS - 1);
+        packed |= (unsigned)bin << (4 * a);
+        atomicAdd(&s_bcount[a][bin], 1);
+        for (int d = 0; d < 3; d++) {
+          atomicMin(&s_blo[a][bin][d], f32_ordered((float)b.lo[d]));
+          atomicMax(&s_bhi[a][bin][d], f32_ordered((float)b.hi[d]));
+        }
+      }
+      s_bin[j] = (unsigned short)packed;
+    }
+    __syncthreads();
+    // one thread per (axis, split behind bin k): surface-area price of the two sides
+    if (tid < 3 * BIG_BINS) {
+      const int a = tid / BIG_BINS, k = tid % BIG_BINS;
+      float cost = inf;
+      if (k < BIG_BINS - 1) {
+        float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+        int nl = 0, nr = 0;
+        for (int q = 0; q <= k; q++)
+          if (s_bcount[a][q]) {
+            nl += s_bcount[a][q];
+            for (int d = 0; d < 3; d++) {
+              lo[d] = fminf(lo[d], f32_from_ordered(s_blo[a][q][d]));
+              hi[d] = fmaxf(hi[d], f32_from_ordered(s_bhi[a][q][d]));
+            }
+          }
+        const float lx = hi[0] - lo[0], ly = hi[1] - lo[1], lz = hi[2] - lo[2];
+        for (int d = 0; d < 3; d++) {
+          lo[d] = inf;
+          hi[d] = -inf;
+        }
+        for (int q = k + 1; q < BIG_BINS; q++)
+          if (s_bcount[a][q]) {
+            nr += s_bcount[a][q];
+            for (int d = 0; d < 3; d++) {
+              lo[d] = fminf(lo[d], f32_from_ordered(s_blo[a][q][d]));
+              hi[d] = fmaxf(hi[d], f32_from_ordered(s_bhi[a][q][d]));
+            }
+          }
+        const float rx = hi[0] - lo[0], ry = hi[1] - lo[1], rz = hi[2] - lo[2];
+        if (nl > 0 && nr > 0) {
+          cost = (lx * ly + ly * lz + lz * lx) * (float)nl + (rx * ry + ry * rz + rz * rx) * (float)nr;
+          if (!(cost == cost)) cost = inf;
+        }
+      }
+      s_cost[tid] = cost;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float best = inf;
+      int at = -1;
+      for (int k = 0; k < 3 * BIG_BINS; k++)
+        if (s_cost[k] < best) {
+          best = s_cost[k];
+          at = k;
+        }
+      s_axis = at < 0 ? -1 : at / BIG_BINS;
+      s_split = at < 0 ? 0 : at % BIG_BINS;
+    }
+    __syncthreads();
+    const int axis = s_axis, split = s_split;
+    int n_left = count / 2;  // no split has a finite price (all centroids in one bin): halves, as they stand
+    if (axis >= 0) {
+      // stable partition of the range: the triangles of bins <= split first
+      n_left = 0;
+      for (int q = 0; q <= split; q++) n_left += s_bcount[axis][q];
+      // pass 2: positions, chunk by chunk of BIG_THREADS consecutive triangles (keeps their order)
+      int done_l = 0, done_r = 0;
+      for (int c0 = f; c0 <= l; c0 += BIG_THREADS) {
+        const int j = c0 + tid;
+        const bool valid = j <= l;
+        const bool left = valid && (((s_bin[j] >> (4 * axis)) & 15) <= split);
+        s_scan[tid] = left ? 1 : 0;
+        __syncthreads();
+        for (int off = 1; off < BIG_THREADS; off <<= 1) {  // inclusive scan
+          const int v = tid >= off ? s_scan[tid - off] : 0;
+          __syncthreads();
+          s_scan[tid] += v;
+          __syncthreads();
+        }
+        const int incl = s_scan[tid];
+        const int chunk_left = s_scan[BIG_THREADS - 1];
+        const int chunk_n = min(BIG_THREADS, l - c0 + 1);
+        if (valid) {
+          const int pos = left ? (f + done_l + incl - 1) : (f + n_left + done_r + (tid - incl));
+          s_tmp[pos] = s_face[j];
+        }
+        done_l += chunk_left;
+        done_r += chunk_n - chunk_left;
+        __syncthreads();
+      }
+      for (int j = f + tid; j <= l; j += BIG_THREADS) s_face[j] = s_tmp[j];
+      __syncthreads();
+    }
+    // the node and its two children
+    if (tid == 0) {
+      int spn = sp - 1;
+      range_first[node] = F + f;
+      range_last[node] = F + l;
+      const int left_last = f + n_left - 1;
+      const int sides[2][2] = {{f, left_last}, {left_last + 1, l}};
+      // the larger side is queued first, so the smaller is split first: the list of waiting ranges
+      // never grows beyond the logarithm of the subtree's size
+      const int first_side = (n_left >= count - n_left) ? 0 : 1;
+      for (int turn = 0; turn < 2; turn++) {
+        const int w = turn == 0 ? first_side : 1 - first_side;
+        const int a = sides[w][0], b = sides[w][1], cnt = b - a + 1;
+        int* slot = w == 0 ? child_l : child_r;
+        if (cnt == 1) {
+          slot[node] = (F + a) | LEAF_BIT;
+          parent_leaf[F + a] = node;
+          continue;
+        }
+        const int child = w == 0 ? F + b : F + a;  // last position of a left child, first of a right one
+        slot[node] = child;
+        parent_inner[child] = node;
+        range_first[child] = F + a;
+        range_last[child] = F + b;
+        if (cnt == 2) {  // the only way to split two triangles
+          child_l[child] = (F + a) | LEAF_BIT;
+          child_r[child] = (F + b) | LEAF_BIT;
+          parent_leaf[F + a] = child;
+          parent_leaf[F + b] = child;
+        } else if (cnt > TREELET) {
+          todo_first[spn] = a;
+          todo_last[spn] = b;
+          todo_node[spn] = child;
+          spn++;
+        }  // 3 .. TREELET triangles: a root with its range, rebuilt below it by k_rebuild_treelets
+      }
+      s_sp = spn;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < m; j += BIG_THREADS) faces[F + j] = s_face[j];
 }
 
 // Node boxes travel between workgroups: written and read with agent-scope atomics (a plain
@@ -759,10 +991,27 @@ int build_lbvh_resident(const double* p1, const double* p2, const double* p3, in
     int *list, *n_list;
     LB_TRY(S.get(&list, (size_t)n_inner));
     LB_TRY(S.get(&n_list, 1));
-    LB_TRY(hipMemset(n_list, 0, sizeof(int)));
-    hipLaunchKernelGGL(k_find_treelets, igrid, block, 0, 0, range_first, range_last, parent_inner, n_inner, list, n_list);
-    LB_TRY(hipGetLastError());
     int count = 0;
+    bool big = true;  // RT_LBVH_BIG_TREELETS=0: the radix tree's splits stay above the 64-triangle subtrees
+    if (const char* e = getenv("RT_LBVH_BIG_TREELETS")) big = atoi(e) != 0;
+    if (big) {
+      LB_TRY(hipMemset(n_list, 0, sizeof(int)));
+      hipLaunchKernelGGL(k_find_treelets, igrid, block, 0, 0, range_first, range_last, parent_inner, n_inner, TREELET + 1,
+                         BIG_TREELET, list, n_list);
+      LB_TRY(hipGetLastError());
+      LB_TRY(hipMemcpy(&count, n_list, sizeof(int), hipMemcpyDeviceToHost));
+      if (count > 0) {
+        hipLaunchKernelGGL(k_rebuild_big_treelets, dim3((unsigned)count), dim3(BIG_THREADS), 0, 0, list, count, d_order,
+                           boxes, child_l, child_r, range_first, range_last, parent_inner, parent_leaf, n_inner);
+        LB_TRY(hipGetLastError());
+      }
+    }
+    LB_TRY(hipMemset(n_list, 0, sizeof(int)));
+    // (two triangles can be split one way only: from three on)
+    hipLaunchKernelGGL(k_find_treelets, igrid, block, 0, 0, range_first, range_last, parent_inner, n_inner, 3, TREELET, list,
+                       n_list);
+    LB_TRY(hipGetLastError());
+    count = 0;
     LB_TRY(hipMemcpy(&count, n_list, sizeof(int), hipMemcpyDeviceToHost));
     if (count > 0) {
       hipLaunchKernelGGL(k_rebuild_treelets, dim3((unsigned)count), dim3(64), 0, 0, list, count, d_order, boxes, child_l,

@@ -31,6 +31,7 @@ KNOBS = [
     ({"RT_SAH_SWEEP": "100000000"}, 0),
     ({"RT_LBVH_TRAV": "1"}, 1),
     ({"RT_LBVH_TREELETS": "0"}, 1),
+    ({"RT_LBVH_BIG_TREELETS": "0"}, 1),
     ({"RT_FRAME_SPLIT": "2"}, 0),
     ({"RT_SHADOW_PASS": "0"}, 0),
     ({"RT_SHADOW_PASS": "1"}, 0),
@@ -209,3 +210,50 @@ def test_two_rank_bench_rehearsal_gives_the_one_gpu_frame(rt):
     assert line2["n_gpus"] == 2 and line1["n_gpus"] == 1
     assert line2["config"]["frame_crc32"] == line1["config"]["frame_crc32"]
     assert line2["config"]["rays_per_frame"] == line1["config"]["rays_per_frame"]
+
+
+@pytest.mark.parametrize("n_tris", [65, 700, 8191, 8192, 8193, 20000])
+def test_device_builder_around_the_large_subtree_limits(rt, O, n_tris):
+    """The device builder splits every maximal subtree of at most 8192 triangles again by the
+    binned surface-area heuristic, down to the 64-triangle subtrees that are rebuilt exactly:
+    meshes just inside, at and beyond both limits against the oracle (its culling mode, which is
+    bit-identical to brute force), and the same frame from the host-built tree."""
+    w = rt.World()
+    scenes.random_scene(w, rt.material, rt, 70 + n_tris, n_prims=3, n_tris=n_tris, hsize=72, vsize=48)
+    w.commit(bvh_builder=1)
+    s = O.Scene()
+    scenes.random_scene(s, O.material, rt, 70 + n_tris, n_prims=3, n_tris=n_tris, hsize=72, vsize=48)
+    s.use_bvh()
+    u8, f64, _ = w.render(want_f64=True)
+    of64, ou8, _ = s.render()
+    assert np.array_equal(u8, ou8)
+    assert np.abs(f64 - of64).max() <= 1e-11
+    h = rt.World()
+    scenes.random_scene(h, rt.material, rt, 70 + n_tris, n_prims=3, n_tris=n_tris, hsize=72, vsize=48)
+    h.commit(bvh_builder=0)
+    hu8, hf64, _ = h.render(want_f64=True)
+    assert np.array_equal(hu8, u8) and np.array_equal(hf64, f64)
+
+
+def test_device_builder_on_thousands_of_coincident_triangles(rt, O):
+    """9000 copies of one triangle (no split separates them: every centroid falls into one bin, the
+    large-subtree rebuild halves the ranges as they stand) and a geometric row of 3000 shrinking
+    ones, built on the device."""
+    w = rt.World()
+    scenes.deep_tree_scene(w, rt.material, rt, n_same=9000, n_line=3000)
+    w.commit(bvh_builder=1)
+    s = O.Scene()
+    scenes.deep_tree_scene(s, O.material, rt, n_same=9000, n_line=3000)
+    s.use_bvh()
+    u8, f64, _ = w.render(want_f64=True)
+    of64, ou8, _ = s.render()
+    assert np.array_equal(u8, ou8)
+    assert np.abs(f64 - of64).max() <= 1e-11
+
+
+def test_host_and_device_trees_render_the_same_1080p_frame(rt):
+    """The default tree is the device-built one; the host SAH build must give the same bytes at
+    the benchmark's size."""
+    a, _, sa = rt.World.example("pawn", 1920, 1080).commit(bvh_builder=0).render(want_stats=True)
+    b, _, sb = rt.World.example("pawn", 1920, 1080).commit().render(want_stats=True)
+    assert np.array_equal(a, b) and sa.rays() == sb.rays()
