@@ -412,8 +412,9 @@ __device__ __forceinline__ bool prim_culled(const DScene& S, int p, const Ray& r
 // ---------------------------------------------------------------------------------------
 // BVH traversal.  The hierarchy only culls; what a triangle test returns is the f64
 // arithmetic of moller_trumbore() above, bit for bit.  Culling itself runs in f32 against
-// 32-byte nodes (both children's boxes as 16-bit steps of a grid over the mesh's padded
-// bounds, rounded outward from padded f64 boxes) and is made conservative analytically:
+// 64-byte four-wide nodes (the four children's boxes as 16-bit steps of a grid over the mesh's
+// padded bounds, rounded outward from padded f64 boxes, and their four child indices / leaf
+// codes) and is made conservative analytically:
 //   * the ray is re-based to where it enters the mesh's root box (f64), so every f32
 //     operand is of the mesh's own magnitude S = max |coordinate|;
 //   * a direction component smaller than 1e-10 of the largest is replaced by that bound:
