@@ -363,7 +363,11 @@ def main():
         # per launch: this rank's share of the frame (1/n of the counters for n > 1)
         ach_gbs = abytes / n / (kernel_ms * 1e-3) / 1e9
         ach_tf = aflops / n / (kernel_ms * 1e-3) / 1e12
-        traffic, pmc, traffic_src = measured_traffic(args.workload, args.pipeline) if n == 1 else (None, {}, None)
+        # the committed PMC passes are of the default build and settings: a run with another tree, mode
+        # or tuning knob gets no counters from them
+        tuned = [k for k in os.environ if k.startswith("RT_") and k not in ("RT_CPU_THREADS", "RT_BENCH_REHEARSAL_ONE_GPU")]
+        as_profiled = n == 1 and args.mode == "f64_parity" and args.bvh == "lbvh" and not tuned
+        traffic, pmc, traffic_src = measured_traffic(args.workload, args.pipeline) if as_profiled else (None, {}, None)
         # what the frame has to move whatever the kernels do: the scene once, the image, every
         # queued ray written and read once (64 B), every shaded call's result node written and
         # read once (96 B) and its flag byte
