@@ -664,7 +664,7 @@ struct TravStack {
 #define RT_TRAV_STACK_COOP(name, scene)                                         \
   RT_TRAV_STACK(name, scene);                                                   \
   __shared__ rtd::u32x4 name##_rays[3 * 64];                                    \
-  __shared__ __attribute__((aligned(16))) unsigned char name##_owners[rtd::COOP_SLOTS]; \
+  __shared__ unsigned char name##_owners[rtd::COOP_SLOTS];                      \
   name.rays = (rtd::lds_u32x4*)(name##_rays);                                   \
   name.owners = (__attribute__((address_space(3))) unsigned char*)(name##_owners)
 
@@ -963,145 +963,6 @@ __device__ __forceinline__ int node_step(const NodeR& N, const CullRay& c, float
   return sp ? st.get(--sp) : -1;
 }
 
-
-// ---- node steps shared between the lanes of a thin wave ----------------------------------------
-// A node step costs the wave the same instructions whether 5 or 60 of its lanes descend.  When at
-// most SHARE_MAX lanes do, the four box tests of each are dealt to four lanes: every descending
-// lane publishes its node, interval, culling ray and stack pointer in LDS (the area the leaf
-// phase uses for its owner table, free during the descent), lane 4g + k tests child k of the
-// g-th descending lane, the four lanes order their children among themselves with three
-// cross-lane compare-exchanges, the lanes holding children that are not visited next write them
-// straight into the owner's stack column, and the owner reads back where it goes next.  The same
-// children are visited or pushed as by node_step(); only who computes changes.
-#ifndef RT_SHARE_NODES
-#define RT_SHARE_NODES 1
-#endif
-constexpr int SHARE_MAX = 16;
-static_assert(48 * SHARE_MAX + 8 * SHARE_MAX <= COOP_SLOTS, "the shared node step's records fit the owner table's area");
-typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-
-template <int MODE>
-__device__ __forceinline__ void quad_cswap(float& key, int& code, const bool low, const int ctrl_tag) {
-  // one compare-exchange between two lanes of a quad: the lower lane keeps the smaller key
-  int pk_bits, pc;
-  if (ctrl_tag == 0) {  // partner: lane ^ 1
-    pk_bits = __builtin_amdgcn_mov_dpp((int)__float_as_uint(key), 0xB1, 0xf, 0xf, true);
-    pc = __builtin_amdgcn_mov_dpp(code, 0xB1, 0xf, 0xf, true);
-  } else if (ctrl_tag == 1) {  // partner: lane ^ 2
-    pk_bits = __builtin_amdgcn_mov_dpp((int)__float_as_uint(key), 0x4E, 0xf, 0xf, true);
-    pc = __builtin_amdgcn_mov_dpp(code, 0x4E, 0xf, 0xf, true);
-  } else {  // lanes 1 and 2 of the quad trade, 0 and 3 see themselves
-    pk_bits = __builtin_amdgcn_mov_dpp((int)__float_as_uint(key), 0xD8, 0xf, 0xf, true);
-    pc = __builtin_amdgcn_mov_dpp(code, 0xD8, 0xf, 0xf, true);
-  }
-  const float pk = __uint_as_float((unsigned)pk_bits);
-  // both lanes of a pair decide on the same two keys (never NaN, see below): equal keys stay
-  const bool take = low ? (pk < key) : (pk > key);
-  key = take ? pk : key;
-  code = take ? pc : code;
-}
-
-// wm: ballot of the descending lanes (cur >= 0), W of them, W <= SHARE_MAX; every lane of the
-// wave calls this; no descending lane's stack may be within three entries of the end of its
-// LDS part (the workers cannot reach a lane's private spill array).
-template <int MODE>
-__device__ __forceinline__ void node_step_shared(const DNode4* nodes, int& cur, int& sp, const CullRay& c, float qlo,
-                                                 float qhi, unsigned long long wm, int W, TravStack& st) {
-  const int lane = threadIdx.x & 63;
-  lds_u32x4* rec = (lds_u32x4*)st.owners;                   // three 16-byte words per descending lane, by rank
-  lds_u64* tab = (lds_u64*)(st.owners + 48 * SHARE_MAX);    // rank -> (lane, sp); after the step: (cur, sp)
-  lds_int* columns = st.lds - lane;                         // entry i of lane l: columns[i * 64 + l]
-  const bool walking = cur >= 0;
-  const int r = __popcll(wm & ((1ull << lane) - 1ull));
-  if (walking) {
-    u32x4 w0, w1, w2;
-    w0.x = (unsigned)cur | (c.sh[0] ? 1u << 28 : 0u) | (c.sh[1] ? 1u << 29 : 0u) | (c.sh[2] ? 1u << 30 : 0u);
-    w0.y = __float_as_uint(qlo);
-    w0.z = __float_as_uint(qhi);
-    w0.w = __float_as_uint(c.a[0]);
-    w1.x = __float_as_uint(c.a[1]);
-    w1.y = __float_as_uint(c.a[2]);
-    w1.z = __float_as_uint(c.nf[0].x);
-    w1.w = __float_as_uint(c.nf[0].y);
-    w2.x = __float_as_uint(c.nf[1].x);
-    w2.y = __float_as_uint(c.nf[1].y);
-    w2.z = __float_as_uint(c.nf[2].x);
-    w2.w = __float_as_uint(c.nf[2].y);
-    rec[3 * r + 0] = w0;
-    rec[3 * r + 1] = w1;
-    rec[3 * r + 2] = w2;
-    tab[r] = (unsigned long long)(unsigned)(lane | (sp << 8));
-  }
-  wave_lds_fence();
-  const int g = lane >> 2, k = lane & 3;
-  const bool work = g < W;
-  float key = __builtin_huge_valf();
-  int code = -1;
-  int o_lane = 0, o_sp = 0;
-  if (work) {
-    const u32x4 w0 = rec[3 * g + 0], w1 = rec[3 * g + 1], w2 = rec[3 * g + 2];
-    const unsigned t = (unsigned)tab[g];
-    o_lane = (int)(t & 255u);
-    o_sp = (int)(t >> 8);
-    CullRay cc;
-    cc.a[0] = __uint_as_float(w0.w);
-    cc.a[1] = __uint_as_float(w1.x);
-    cc.a[2] = __uint_as_float(w1.y);
-    cc.nf[0].x = __uint_as_float(w1.z);
-    cc.nf[0].y = __uint_as_float(w1.w);
-    cc.nf[1].x = __uint_as_float(w2.x);
-    cc.nf[1].y = __uint_as_float(w2.y);
-    cc.nf[2].x = __uint_as_float(w2.z);
-    cc.nf[2].y = __uint_as_float(w2.w);
-    cc.sh[0] = (w0.x & (1u << 28)) ? 16 : 0;
-    cc.sh[1] = (w0.x & (1u << 29)) ? 16 : 0;
-    cc.sh[2] = (w0.x & (1u << 30)) ? 16 : 0;
-    const uint32_t* np = reinterpret_cast<const uint32_t*>(nodes + (w0.x & 0x0fffffffu));
-    const uint32_t q[3] = {np[3 * k], np[3 * k + 1], np[3 * k + 2]};
-    const int child = (int)np[12 + k];
-    float tn, tf;
-    slab32(q, cc, tn, tf);
-    const bool h = fmaxf(tn, __uint_as_float(w0.y)) <= fminf(tf, __uint_as_float(w0.z));
-    float kk = (MODE == Q_PRED) ? -tf : tn;
-    kk = (kk == kk) ? kk : -__builtin_huge_valf();  // no NaN among the keys: the lanes must agree on every comparison
-    key = h ? kk : __builtin_huge_valf();
-    code = h ? child : -1;  // (an empty slot's code is -1 already)
-  }
-  if (MODE != Q_ANY) {  // shadow queries take the hit children as they come
-    quad_cswap<MODE>(key, code, (k & 1) == 0, 0);  // (0,1) (2,3)
-    quad_cswap<MODE>(key, code, (k & 2) == 0, 1);  // (0,2) (1,3)
-    quad_cswap<MODE>(key, code, k == 1, 2);        // (1,2)
-  }
-  const unsigned long long hm = __ballot(code != -1);
-  const unsigned mask4 = (unsigned)(hm >> (lane & ~3)) & 0xFu;  // the hit children of my quad, in visiting order
-  const int first = mask4 ? __ffs((int)mask4) - 1 : 0;
-  const int hits = __popc(mask4);
-  if (work && code != -1 && k != first)  // not visited next: onto the owner's stack, the farthest lowest
-    columns[(o_sp + __popc(mask4 >> (k + 1))) * 64 + o_lane] = code;
-  const int first_code = __shfl(code, (lane & ~3) + first, 64);
-  if (work && k == 0) {
-    int ncur, nsp;
-    if (hits) {
-      ncur = first_code;
-      nsp = o_sp + hits - 1;
-    } else if (o_sp > 0) {
-      nsp = o_sp - 1;
-      ncur = columns[nsp * 64 + o_lane];
-    } else {
-      ncur = -1;
-      nsp = 0;
-    }
-    tab[g] = (unsigned long long)(unsigned)ncur | ((unsigned long long)(unsigned)nsp << 32);
-  }
-  wave_lds_fence();
-  if (walking) {
-    const unsigned long long t = tab[r];
-    cur = (int)(unsigned)t;
-    sp = (int)(unsigned)(t >> 32);
-  }
-  wave_lds_fence();
-}
-
 // Walks every mesh.  Returns true as soon as a Q_ANY query is satisfied.
 template <int MODE, bool STATS>
 __device__ inline bool traverse_meshes(const DScene& S, const Ray& ray, Query& q, Counters& cnt,
@@ -1245,24 +1106,16 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, con
     unsigned long long visited = 0;
     while (__ballot(cur != -1) != 0ull) {  // wave-uniform
       const int alive = __popcll(__ballot(cur != -1));
-      // the descent: until fewer than half of the lanes still walking this mesh are descending
-      // (the others hold a leaf); a lane that descends takes at least one step
-      for (bool first_step = true;; first_step = false) {  // wave-uniform
-        const unsigned long long wm = __ballot(cur >= 0);
-        const int W = __popcll(wm);
-        if (W == 0 || (!first_step && W * 2 < alive)) break;
-        if (STATS && cur >= 0) {
+      while (cur >= 0) {
+        const NodeR N = load_node(S.nodes + cur);
+        if (STATS) {
           if (wave_leader()) cnt.node_wave_steps++;
           cnt.nodes_visited++;
           visited++;
           if (visited > cnt.max_nodes) cnt.max_nodes = visited;
         }
-        if (RT_SHARE_NODES && W <= SHARE_MAX && __ballot(cur >= 0 && sp + 3 > LDS_STACK) == 0ull) {
-          node_step_shared<MODE>(S.nodes, cur, sp, c, qlo, qhi, wm, W, st);
-        } else if (cur >= 0) {
-          const NodeR N = load_node(S.nodes + cur);
-          cur = node_step<MODE>(N, c, qlo, qhi, sp, st);
-        }
+        cur = node_step<MODE>(N, c, qlo, qhi, sp, st);
+        if (__popcll(__ballot(cur >= 0)) * 2 < alive) break;
       }
       // ---- shared leaf phase (all 64 lanes)
       const bool has_leaf = cur <= -2;
