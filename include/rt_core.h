@@ -261,7 +261,12 @@ int rt_scene_device_count(const rt_scene*);
  * Limits: 1 <= depth <= 8; at most RT_NOALLOC_MAX_TILES tiles per call (RT_ERR_UNSUPPORTED with
  * a message otherwise: pass a larger tile_step and call once per shard).  All calls on one GPU
  * share the array: calls that overlap on one GPU (different streams, different scenes) race;
- * calls on one stream, or ordered by events, do not. */
+ * calls on one stream, or ordered by events, do not.  It always runs the wave-shared kernels
+ * (the RT_SHARE_LEAVES and RT_SHADOW_PASS knobs do not apply to it; the frames are the same bits
+ * either way), and serves a scene committed with rt_scene_commit_multi like any other (on its
+ * first GPU, row-major).  The per-GPU address of the array is looked up when a scene is
+ * committed: two host threads committing different scenes at the same moment would both store
+ * the same value. */
 #define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
 #define RT_NOALLOC_MAX_TILES 8192
 int rt_render_device_noalloc(rt_scene*, const rt_camera*, int depth, int mode, int tile_first,
