@@ -257,3 +257,29 @@ def test_host_and_device_trees_render_the_same_1080p_frame(rt):
     a, _, sa = rt.World.example("pawn", 1920, 1080).commit(bvh_builder=0).render(want_stats=True)
     b, _, sb = rt.World.example("pawn", 1920, 1080).commit().render(want_stats=True)
     assert np.array_equal(a, b) and sa.rays() == sb.rays()
+
+
+def test_multi_entry_points_refuse_bad_calls(rt):
+    """rt_render_multi / rt_render_multi_f64: a scene committed for one GPU the ordinary way, no
+    output at all, a camera of no size — each refused with a status and a message, none fatal."""
+    import ctypes as C
+    single = rt.World.example("cover", 64, 48).commit()
+    with pytest.raises(rt.RtError, match="rt_scene_commit_multi"):
+        single.render_multi()
+    w = rt.World.example("cover", 64, 48).commit_multi([0])
+    cam = w.camera_abi()
+    rc = w.L.rt_render_multi_f64(w.scene, C.byref(cam), 5, rt.MODE_F64_PARITY, rt.PIPELINE_WAVEFRONT, None, None, None,
+                                 None, None)
+    assert rc != 0 and b"no output buffer" in w.L.rt_last_error()
+    rc = w.L.rt_render_multi(w.scene, C.byref(cam), 5, rt.MODE_F64_PARITY, rt.PIPELINE_WAVEFRONT, None, None, None)
+    assert rc != 0 and b"no output buffer" in w.L.rt_last_error()
+    bad = rt.CameraABI()
+    C.memmove(C.byref(bad), C.byref(cam), C.sizeof(cam))
+    bad.hsize = 0
+    u8 = np.zeros(64 * 48 * 3, dtype=np.uint8)
+    rc = w.L.rt_render_multi(w.scene, C.byref(bad), 5, rt.MODE_F64_PARITY, rt.PIPELINE_WAVEFRONT,
+                             u8.ctypes.data_as(C.POINTER(C.c_uint8)), None, None)
+    assert rc != 0
+    got, _ = w.render_multi()  # and the scene still renders
+    ref, _, _ = single.render()
+    assert np.array_equal(got, ref)
