@@ -180,38 +180,6 @@ def test_render_multi_f64_equals_render(rt, O):
     assert np.array_equal(u8, ref_u8) and np.array_equal(f64, ref_f64)
 
 
-def test_two_rank_bench_rehearsal_gives_the_one_gpu_frame(rt):
-    """bench.py as the driver launches it for N = 2 (one process per rank under
-    torch.distributed.run: tile shards, gather to rank 0, de-tile), rehearsed on this one GPU
-    with gloo instead of RCCL: the frame's CRC must be the one-GPU run's."""
-    import json
-    import os
-    import socket
-    import subprocess
-    import sys
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--workload", "pawn1080", "--steps", "2", "--warmup", "1", "--sustain-s", "0", "--no-cpu-baseline"]
-    env = dict(os.environ)
-    one = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1"] + common,
-                         capture_output=True, text=True, timeout=300, env=env, cwd=repo)
-    assert one.returncode == 0, one.stderr[-2000:]
-    line1 = json.loads(one.stdout.strip().splitlines()[-1])
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env["RT_BENCH_REHEARSAL_ONE_GPU"] = "1"
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port),
-                          os.path.join(repo, "bench.py"), "--gpus", "2"] + common,
-                         capture_output=True, text=True, timeout=300, env=env, cwd=repo)
-    assert two.returncode == 0, two.stderr[-2000:]
-    line2 = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
-    assert line2["n_gpus"] == 2 and line1["n_gpus"] == 1
-    assert line2["config"]["frame_crc32"] == line1["config"]["frame_crc32"]
-    assert line2["config"]["rays_per_frame"] == line1["config"]["rays_per_frame"]
-
-
 @pytest.mark.parametrize("n_tris", [65, 700, 8191, 8192, 8193, 20000])
 def test_device_builder_around_the_large_subtree_limits(rt, O, n_tris):
     """The device builder splits every maximal subtree of at most 8192 triangles again by the
@@ -283,3 +251,35 @@ def test_multi_entry_points_refuse_bad_calls(rt):
     got, _ = w.render_multi()  # and the scene still renders
     ref, _, _ = single.render()
     assert np.array_equal(got, ref)
+
+
+def test_two_rank_bench_rehearsal_gives_the_one_gpu_frame(rt):
+    """bench.py as the driver launches it for N = 2 (one process per rank under
+    torch.distributed.run: tile shards, gather to rank 0, de-tile), rehearsed on this one GPU
+    with gloo instead of RCCL: the frame's CRC must be the one-GPU run's."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", "pawn1080", "--steps", "2", "--warmup", "1", "--sustain-s", "0", "--no-cpu-baseline"]
+    env = dict(os.environ)
+    one = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1"] + common,
+                         capture_output=True, text=True, timeout=300, env=env, cwd=repo)
+    assert one.returncode == 0, one.stderr[-2000:]
+    line1 = json.loads(one.stdout.strip().splitlines()[-1])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env["RT_BENCH_REHEARSAL_ONE_GPU"] = "1"
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(repo, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=300, env=env, cwd=repo)
+    assert two.returncode == 0, two.stderr[-2000:]
+    line2 = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line2["n_gpus"] == 2 and line1["n_gpus"] == 1
+    assert line2["config"]["frame_crc32"] == line1["config"]["frame_crc32"]
+    assert line2["config"]["rays_per_frame"] == line1["config"]["rays_per_frame"]
