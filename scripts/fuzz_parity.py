@@ -23,8 +23,11 @@ for seed in range(first, first + count):
     u8, f64, st = w.render(pipeline=pipe, want_f64=True, want_stats=True)
     s.use_bvh()
     of64, ou8, cnt = s.render()
+    # the frame again: the kernels without counters, issued from the remembered queue lengths
+    u8b, f64b, _ = w.render(pipeline=pipe, want_f64=True)
     ok = np.array_equal(u8, ou8) and np.abs(f64 - of64).max() <= 1e-11 and \
-        (st.rays_primary, st.rays_shadow, st.rays_reflect, st.rays_refract) == (cnt["primary"], cnt["shadow"], cnt["reflect"], cnt["refract"])
+        (st.rays_primary, st.rays_shadow, st.rays_reflect, st.rays_refract) == (cnt["primary"], cnt["shadow"], cnt["reflect"], cnt["refract"]) and \
+        np.array_equal(u8b, u8) and np.array_equal(f64b, f64)
     if not ok:
         bad += 1
         d = np.abs(u8.astype(int) - ou8.astype(int)).max(axis=-1)
