@@ -116,6 +116,7 @@ struct rt_scene {
     size_t wf_keys_cap[MAX_DEPTH + 1] = {};
     size_t wf_perm_cap[MAX_DEPTH + 1] = {};
     unsigned int* wf_hist = nullptr;  // SORT_BINS counters (zero between uses) + SORT_BINS cursors
+    unsigned int* wf_cursor[MAX_DEPTH + 1] = {};  // placed emission: SORT_BINS tickets per level, zeroed per frame
     size_t wf_task_cap[MAX_DEPTH + 1] = {};
     size_t wf_node_cap[MAX_DEPTH + 1] = {};
     size_t wf_live_cap[MAX_DEPTH + 1] = {};
@@ -177,6 +178,9 @@ struct rt_scene {
     bool fast = false;
     long long n[MAX_DEPTH + 1] = {}, front[MAX_DEPTH + 1] = {};
     long long shadow[MAX_DEPTH + 1] = {};  // hits per level = entries of the level's shadow queue (-1: not known)
+    // device, per sorted level: start of every key's run in the level's queue (SORT_BINS entries),
+    // left behind by the frame that was rendered with sort passes; owned by the plan list
+    unsigned int* place[MAX_DEPTH + 1] = {};
   };
   std::vector<WfPlan> wf_plans;  // most recent last, at most WF_MAX_PLANS
   // A wavefront frame is rendered as frame_split interleaved tile shards on streams of the
@@ -184,10 +188,10 @@ struct rt_scene {
   // shard's level runs under another shard's work (RT_FRAME_SPLIT, 1 = off).
   int frame_split = 0;  // 0: decided per frame (see render_device_fixed)
   // coherence sort of the ray queues (see SortGrid): grid over the world-space bounds of the
-  // geometry; with RT_SORT_RAYS=1 the queues of level >= sort_min_level (RT_SORT_MIN_LEVEL) are sorted
+  // geometry; unless RT_SORT_RAYS=0 the queues of level >= sort_min_level (RT_SORT_MIN_LEVEL) are kept in key order
   double sort_lo[3] = {0, 0, 0}, sort_inv_cell[3] = {0, 0, 0};
   bool sort_enabled = false;
-  int sort_min_level = 2;
+  int sort_min_level = 1;
   std::vector<hipStream_t> split_streams;
   std::vector<hipStream_t> recent_streams;  // caller streams of the last four wavefront frames
   struct Multi* multi = nullptr;  // rt_scene_commit_multi: replicas on other GPUs, RCCL, buffers
@@ -204,6 +208,13 @@ static constexpr size_t WF_MAX_PLANS = 64;
 constexpr int WF_OVERFLOW_SLOT = 2 * (MAX_DEPTH + 1);
 constexpr int WF_SHADOW_SLOT0 = 2 * (MAX_DEPTH + 2);
 constexpr int WF_N_COUNTS = WF_SHADOW_SLOT0 + MAX_DEPTH + 1;
+// a plan that leaves the list takes its device tables with it (the scene's device must be current)
+static void drop_plan(rt_scene::WfPlan& p) {
+  for (int l = 0; l <= MAX_DEPTH; l++) {
+    if (p.place[l]) (void)hipFree(p.place[l]);
+    p.place[l] = nullptr;
+  }
+}
 
 static bool affine_rows(const double* m16, double* out12, std::string& why) {
   if (!(m16[12] == 0.0 && m16[13] == 0.0 && m16[14] == 0.0 && m16[15] == 1.0)) {
@@ -612,6 +623,39 @@ __device__ __forceinline__ void hist_add(unsigned int* hist, unsigned int key) {
     todo &= ~same;
   }
 }
+// A frame rendered before with its queues sorted has left, per level, where every key's run of
+// tasks starts (the counting sort's exclusive prefix).  The same frame again needs no sort
+// passes: the emitting kernel writes each task straight to its place in key order — start of the
+// key's run plus a ticket from the key's cursor — and the next level reads its queue front to back.
+struct Placement {
+  const unsigned int* off;  // next level: start of every key's run (null: tasks are appended as they come)
+  unsigned int* cur;        // next level: tickets per key, zero when the frame starts
+  int ordered_in;           // this level's queue is already in key order: task i is call i
+};
+// The place of one emitted task.  Lanes that share the first lane's key take their tickets with
+// one atomic (a wave of floor reflections has one or two keys); after a few such groups the
+// rest take theirs one by one.
+__device__ __forceinline__ unsigned int place_position(const Placement& P, unsigned int key) {
+  unsigned long long todo = __ballot(1);
+  const int lane = (int)__lane_id();
+  unsigned int pos = 0;
+  bool placed = false;
+  for (int turn = 0; turn < 4 && todo; turn++) {  // uniform over the lanes that came in
+    const int leader = __ffsll((long long)todo) - 1;
+    const unsigned int k = (unsigned int)__builtin_amdgcn_readlane((int)key, leader);
+    const unsigned long long same = __ballot(key == k);
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(&P.cur[k], (unsigned int)__popcll(same));
+    base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+    if (key == k) {
+      pos = P.off[k] + base + (unsigned int)__popcll(same & ((1ull << lane) - 1ull));
+      placed = true;
+    }
+    todo &= ~same;
+  }
+  if (!placed) pos = P.off[key] + atomicAdd(&P.cur[key], 1u);
+  return pos;
+}
 // exclusive prefix sum of the histogram into `cursor` (one block); leaves the histogram zeroed
 __global__ void __launch_bounds__(1024) k_wf_sort_scan(unsigned int* hist, unsigned int* cursor) {
   constexpr int PER = SORT_BINS / 1024;
@@ -677,7 +721,7 @@ template <bool STATS>
 __device__ __forceinline__ bool emit_result(const ShadeOut& so, const C3& surface, WfNode& nd, long long i,
                                             WfTask* next, unsigned int* next_count, unsigned int next_cap,
                                             int spawn, Counters& cnt, const SortGrid& grid,
-                                            unsigned int* next_keys, unsigned int* hist) {
+                                            unsigned int* next_keys, unsigned int* hist, const Placement& place) {
   nd.surface[0] = surface.r;
   nd.surface[1] = surface.g;
   nd.surface[2] = surface.b;
@@ -689,7 +733,8 @@ __device__ __forceinline__ bool emit_result(const ShadeOut& so, const C3& surfac
   }
   if (so.do_reflect) {
     if (spawn) {
-      unsigned int idx = atomicAdd(next_count, 1u);
+      // (placed: the queue holds exactly the tasks of the frame that left the plan behind)
+      const unsigned int idx = place.off ? place_position(place, sort_key(grid, so.reflect_ray, 1u)) : atomicAdd(next_count, 1u);
       if (idx < next_cap) {
         WfTask& T = next[idx];
         T.o[0] = so.reflect_ray.o.x;
@@ -713,9 +758,9 @@ __device__ __forceinline__ bool emit_result(const ShadeOut& so, const C3& surfac
   }
   if (so.do_refract) {
     if (spawn) {
-      unsigned int idx = atomicAdd(next_count + 1, 1u);
+      const unsigned int idx = place.off ? place_position(place, sort_key(grid, so.refract_ray, 0u)) : atomicAdd(next_count + 1, 1u);
       if (idx < next_cap) {
-        WfTask& T = next[next_cap - 1 - idx];
+        WfTask& T = next[place.off ? idx : next_cap - 1 - idx];
         T.o[0] = so.refract_ray.o.x;
         T.o[1] = so.refract_ray.o.y;
         T.o[2] = so.refract_ray.o.z;
@@ -788,8 +833,8 @@ wf_level_body(const DScene& S, const DCamera& cam, const PixelMap& pm, const WfT
               WfTask* next,
               unsigned int* next_count, unsigned int next_cap, int spawn, unsigned long long* counters,
               const unsigned int* counts_in, unsigned int* overflow, const SortGrid& grid, const unsigned int* perm,
-              unsigned int* next_keys, unsigned int* hist, WfShadow* shadow_q, unsigned int* shadow_count,
-              TravStack& st, const long long block) {
+              unsigned int* next_keys, unsigned int* hist, const Placement& place, WfShadow* shadow_q,
+              unsigned int* shadow_count, TravStack& st, const long long block) {
   static_assert(WF_BLOCK == 64, "the traversal stack is laid out for 64-lane blocks");
   static_assert(COOP || !FAST, "the f32 search exists on the shared leaf tests only");
   static_assert(COOP || !SHQ, "the shadow pass exists on the cooperative kernels only");
@@ -838,7 +883,7 @@ wf_level_body(const DScene& S, const DCamera& cam, const PixelMap& pm, const WfT
       // longest walks) take the lowest indices, so they are dispatched first and the level's
       // tail is made of cheap rays.
       const long long n_back = n - n_front;
-      const WfTask& T = tasks[perm ? (long long)perm[i] : (i < n_back ? (long long)cap - 1 - i : i - n_back)];
+      const WfTask& T = tasks[place.ordered_in ? i : perm ? (long long)perm[i] : (i < n_back ? (long long)cap - 1 - i : i - n_back)];
       ray = {v3(T.o[0], T.o[1], T.o[2]), v3(T.d[0], T.d[1], T.d[2])};
       nd.parent = T.parent;
       nd.coef = T.coef;
@@ -897,7 +942,7 @@ wf_level_body(const DScene& S, const DCamera& cam, const PixelMap& pm, const WfT
       over = pr.over;
       ShadeOut so;
       finish_optics(S.mats[pr.mat_index], ray, pr, n1, n2, so);
-      has_children = emit_result<STATS>(so, surface, nd, i, next, next_count, next_cap, spawn, cnt, grid, next_keys, hist);
+      has_children = emit_result<STATS>(so, surface, nd, i, next, next_count, next_cap, spawn, cnt, grid, next_keys, hist, place);
     }
     if (SHQ) {
       // The light loop goes to the shadow pass: the hits of the wave take consecutive slots of
@@ -956,7 +1001,7 @@ wf_level_body(const DScene& S, const DCamera& cam, const PixelMap& pm, const WfT
       if (trace_closest<STATS>(S, ray, h, cnt, st)) {
         ShadeOut so;
         shade_hit_local<STATS>(S, ray, h, so, cnt, st);
-        has_children = emit_result<STATS>(so, so.surface, nd, i, next, next_count, next_cap, spawn, cnt, grid, next_keys, hist);
+        has_children = emit_result<STATS>(so, so.surface, nd, i, next, next_count, next_cap, spawn, cnt, grid, next_keys, hist, place);
       }
     }
   }
@@ -1073,15 +1118,15 @@ k_wf_level(DScene S, DCamera cam, PixelMap pm, const WfTask* tasks, long long n,
            WfTask* next,
            unsigned int* next_count, unsigned int next_cap, int spawn, unsigned long long* counters,
            const unsigned int* counts_in, unsigned int* overflow, SortGrid grid, const unsigned int* perm,
-           unsigned int* next_keys, unsigned int* hist, WfShadow* shadow_q, unsigned int* shadow_count,
-           ShadowPass before, long long level_blocks) {
+           unsigned int* next_keys, unsigned int* hist, Placement place, WfShadow* shadow_q,
+           unsigned int* shadow_count, ShadowPass before, long long level_blocks) {
   RT_TRAV_STACK_COOP(st, S);
   const long long block = wf_block_index();
   if (!SHQ || PRIMARY || block < level_blocks)
     wf_level_body<STATS, PRIMARY, FAST, COOP, SHQ>(S, cam, pm, tasks, n, n_front, cap, nodes, live, parents, out_f64,
                                                    out_u8, next, next_count, next_cap, spawn, counters, counts_in,
-                                                   overflow, grid, perm, next_keys, hist, shadow_q, shadow_count, st,
-                                                   block);
+                                                   overflow, grid, perm, next_keys, hist, place, shadow_q, shadow_count,
+                                                   st, block);
   else
     wf_shadow_body<STATS, FAST>(S, before, out_f64, out_u8, counters, st, block - level_blocks);
 }
@@ -1157,6 +1202,7 @@ void rt_scene_destroy(rt_scene* s) {
       if (q.device) (void)hipFree(q.device);
       if (q.pinned) (void)hipHostFree(q.pinned);
     }
+    for (rt_scene::WfPlan& p : s->wf_plans) drop_plan(p);
     for (rt_scene::WfState* w : s->wf_states) {
       for (int l = 0; l <= MAX_DEPTH; l++) {
         if (w->wf_tasks[l]) (void)hipFree(w->wf_tasks[l]);
@@ -1165,6 +1211,7 @@ void rt_scene_destroy(rt_scene* s) {
         if (w->wf_shadow[l]) (void)hipFree(w->wf_shadow[l]);
         if (w->wf_keys[l]) (void)hipFree(w->wf_keys[l]);
         if (w->wf_perm[l]) (void)hipFree(w->wf_perm[l]);
+        if (w->wf_cursor[l]) (void)hipFree(w->wf_cursor[l]);
       }
       if (w->wf_counts) (void)hipFree(w->wf_counts);
       if (w->wf_hist) (void)hipFree(w->wf_hist);
@@ -1577,11 +1624,14 @@ int rt_scene_commit(rt_scene* s, int device, int bvh_builder) {
       s->sort_lo[a] = glo[a];
       s->sort_inv_cell[a] = (ext > 0.0 && std::isfinite(ext)) ? (double)(1 << SORT_CELL_BITS) / ext : 0.0;
     }
-    // Off unless asked for: measured on MI355X the sort raises the node loop's lane occupancy at
-    // the deep levels of the pawn frame from 24-32 to 32-37 of 64 and shortens those levels by
-    // 9-11 %, which its own passes (30 + 45-80 us per level) give back.
+    // On unless RT_SORT_RAYS=0.  Measured on MI355X the order raises the node loop's lane occupancy
+    // at the deep levels of the pawn frame from 24-32 to 32-37 of 64 and shortens those levels by
+    // 9-11 %.  The sort's own passes (30 + 45-80 us per level) give that back, but only the first
+    // exact render of a frame runs them: it leaves the start of every key's run with the frame's
+    // plan, and the same frame afterwards places its tasks in key order as it emits them
+    // (pawn 1080p 2.26 instead of 2.40 ms, pawn 8K 31.2 instead of 34.9, tea set 0.555 / 0.567).
     const char* want_sort = getenv("RT_SORT_RAYS");
-    s->sort_enabled = s->sort_enabled && want_sort && atoi(want_sort) != 0;
+    s->sort_enabled = s->sort_enabled && (!want_sort || atoi(want_sort) != 0);
     if (const char* e = getenv("RT_SORT_MIN_LEVEL")) s->sort_min_level = std::max(1, atoi(e));
   }
   if ((rc = upload(s, groups, &s->d.groups))) return rc;
@@ -1725,10 +1775,14 @@ static void resolve_estimate(rt_scene* s, rt_scene::WfState* w, int* complete) {
   for (int l = 0; l < plan.levels; l++) plan.shadow[l] = h[WF_SHADOW_SLOT0 + l];
   for (size_t i = 0; i < s->wf_plans.size(); i++)
     if (s->wf_plans[i].key == plan.key && same_frame(s->wf_plans[i].id, plan.id)) {
+      drop_plan(s->wf_plans[i]);
       s->wf_plans.erase(s->wf_plans.begin() + (long)i);
       break;
     }
-  if (s->wf_plans.size() >= WF_MAX_PLANS) s->wf_plans.erase(s->wf_plans.begin());
+  if (s->wf_plans.size() >= WF_MAX_PLANS) {
+    drop_plan(s->wf_plans.front());
+    s->wf_plans.erase(s->wf_plans.begin());
+  }
   s->wf_plans.push_back(plan);
 }
 
@@ -1756,6 +1810,14 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     plan.fast = fast;
     plan.n[0] = plan.front[0] = ntiles * (long long)(RT_TILE * RT_TILE);
   }
+  // a plan under construction owns the tables it allocates until it joins the list
+  struct PlanGuard {
+    rt_scene::WfPlan* p;
+    bool armed;
+    ~PlanGuard() {
+      if (armed) drop_plan(*p);
+    }
+  } plan_guard{&plan, !planned};
   // A frame never seen before normally costs a host read-back per level (below).  When the
   // caller has asked for it (rt_render_device_estimated) and the scene has rendered a frame of
   // the same size, depth and mode, the new frame is issued without any read-back instead: grids
@@ -1818,7 +1880,10 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
   long long level_n[MAX_DEPTH + 1];
   int levels = 0;
   bool spawned[MAX_DEPTH + 1] = {};
-  bool sorted_in = false;  // the queue the current level reads has been sorted
+  bool sorted_in = false;   // the queue the current level reads has been sorted (read through a permutation)
+  bool ordered_in = false;  // ... or was filled in key order (read front to back)
+  bool captured = false;    // this frame has added tables to its plan
+  const long long level_n0 = n;  // calls of level 0 = pixels of the shard's tiles
   int rc;
   for (int l = 0; l < depth; l++) {
     bool spawn = (l + 1 < depth);
@@ -1832,7 +1897,14 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
         return rc;
     }
     // the queue this level fills is sorted before the next level reads it
-    const bool sort_next = spawn && s->sort_enabled && (l + 1) >= s->sort_min_level;
+    // (a frame issued on an estimate runs unsorted: its one render would pay the passes for nothing)
+    // ... nor is a short queue kept in order (under a sixteenth of the shard's pixels: the order of
+    // emission, pixel patch by pixel patch, is as good for the few rays of a scene with little
+    // recursion — the 64 mirror spheres of the 1 M-triangle frame: 1 % slower sorted); a planned
+    // frame knows the length beforehand, a new one learns it after the level
+    const long long sort_least = level_n0 / 16;
+    const bool sort_next = spawn && s->sort_enabled && (l + 1) >= s->sort_min_level && !estimate &&
+                           !(planned && (l + 1 >= plan.levels || plan.n[l + 1] < sort_least));
     if (sort_next) {
       if ((rc = wf_ensure(&w->wf_keys[l + 1], &w->wf_keys_cap[l + 1], w->wf_task_cap[l + 1], sizeof(unsigned int))))
         return rc;
@@ -1847,8 +1919,18 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
       sgrid.inv_cell[a] = s->sort_inv_cell[a];
     }
     sgrid.enabled = sort_next ? 1 : 0;
+    // A planned frame whose plan knows where every key's run starts places its tasks in key
+    // order as it emits them: no keys, no histogram, no sort passes.
+    Placement place{nullptr, nullptr, ordered_in ? 1 : 0};
+    const bool place_next = sort_next && planned && plan.place[l + 1] != nullptr;
+    if (place_next) {
+      if (!w->wf_cursor[l + 1]) HIP_TRY(hipMalloc(&w->wf_cursor[l + 1], (size_t)SORT_BINS * sizeof(unsigned int)));
+      HIP_TRY(hipMemsetAsync(w->wf_cursor[l + 1], 0, (size_t)SORT_BINS * sizeof(unsigned int), st));
+      place.off = plan.place[l + 1];
+      place.cur = w->wf_cursor[l + 1];
+    }
     const unsigned int* perm_in = sorted_in ? static_cast<const unsigned int*>(w->wf_perm[l]) : nullptr;
-    unsigned int* keys_next = sort_next ? static_cast<unsigned int*>(w->wf_keys[l + 1]) : nullptr;
+    unsigned int* keys_next = (sort_next && !place_next) ? static_cast<unsigned int*>(w->wf_keys[l + 1]) : nullptr;
     // With the shadow pass, this launch also carries the light loops the level before has queued
     // (behind the level's own waves): as many waves as that level had hits when the count is
     // known (a planned frame), as many as it had calls otherwise; the kernel reads the true count.
@@ -1880,7 +1962,7 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
                      nodes, static_cast<uint8_t*>(w->wf_live[l]), parents, d_f64, d_u8, tnext, cnt_next, cap,   \
                      spawn ? 1 : 0, s->d_counters,                                                              \
                      (estimate && l > 0) ? w->wf_counts + 2 * l : (const unsigned int*)nullptr,                \
-                     w->wf_counts + OVERFLOW_SLOT, sgrid, perm_in, keys_next, w->wf_hist,                       \
+                     w->wf_counts + OVERFLOW_SLOT, sgrid, perm_in, keys_next, w->wf_hist, place,                \
                      static_cast<WfShadow*>(w->wf_shadow[l]), w->wf_counts + WF_SHADOW_SLOT0 + l, before,      \
                      level_blocks)
 #define WF_LAUNCH2(ST, PR)                    \
@@ -1935,12 +2017,26 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     }
     cap_in = cap;
     sorted_in = false;
-    if (sort_next) {
+    ordered_in = place_next;
+    if (sort_next && !place_next && n < sort_least) {
+      // a new frame's queue turned out short: it stays as it was filled; the histogram is cleared
+      // for its next use
+      HIP_TRY(hipMemsetAsync(w->wf_hist, 0, (size_t)SORT_BINS * sizeof(unsigned int), st));
+    } else if (sort_next && !place_next) {
       // counting sort of the queue just filled: the histogram is complete, one block turns it
       // into start positions (and zeroes it for its next use), one pass deals out the positions
       hipLaunchKernelGGL(k_wf_sort_scan, dim3(1), dim3(1024), 0, st, w->wf_hist, w->wf_hist + SORT_BINS);
       HIP_TRY(hipGetLastError());
       s->launches++;
+      if (n > 0 && !plan.place[l + 1]) {
+        // the start positions stay with the frame's plan: the same frame again places its tasks
+        // there as it emits them (a plan that came from an estimated frame gets them on the
+        // frame's first exact render)
+        HIP_TRY(hipMalloc(&plan.place[l + 1], (size_t)SORT_BINS * sizeof(unsigned int)));
+        captured = true;
+        HIP_TRY(hipMemcpyAsync(plan.place[l + 1], w->wf_hist + SORT_BINS, (size_t)SORT_BINS * sizeof(unsigned int),
+                               hipMemcpyDeviceToDevice, st));
+      }
       if (n > 0) {
         if ((rc = wf_ensure(&w->wf_perm[l + 1], &w->wf_perm_cap[l + 1], (size_t)n, sizeof(unsigned int)))) return rc;
         hipLaunchKernelGGL(k_wf_sort_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys_next, n, n_front,
@@ -1952,6 +2048,9 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
       }
     }
     if (n == 0 && !estimate) break;
+  }
+  if (planned && captured) {  // the list's entry of this plan (moved to the back above) takes the new tables
+    for (int l = 0; l <= MAX_DEPTH; l++) s->wf_plans.back().place[l] = plan.place[l];
   }
   if (levels > 0 && s->shadow_pass && (fast || s->share_leaves)) {
     // the light loops of the last level: nothing follows that could carry them
@@ -1993,8 +2092,12 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     HIP_TRY(hipStreamSynchronize(st));  // the last level's hit count
     for (int l = 0; l <= MAX_DEPTH; l++)
       plan.shadow[l] = (l < levels && s->shadow_pass) ? (long long)w->wf_counts_host[WF_SHADOW_SLOT0 + l] : -1;
-    if (s->wf_plans.size() >= WF_MAX_PLANS) s->wf_plans.erase(s->wf_plans.begin());
+    if (s->wf_plans.size() >= WF_MAX_PLANS) {
+      drop_plan(s->wf_plans.front());
+      s->wf_plans.erase(s->wf_plans.begin());
+    }
     s->wf_plans.push_back(plan);
+    plan_guard.armed = false;
     if (getenv("RT_TRACE_LEVELS"))  // queue length of every level of a newly planned frame
       for (int l = 0; l < levels; l++) fprintf(stderr, "rt: level %d: %lld tasks\n", l, level_n[l]);
   }
@@ -2246,8 +2349,8 @@ int rt_render_device_noalloc(rt_scene* s, const rt_camera* cam, int depth, int m
   hipLaunchKernelGGL((k_wf_level<false, PR, FA, true, false>), grid, block, 0, st, s->d, dc, pm, tin, n, n, cap_in, \
                      nodes, live, parents, d_rgb_f64, d_rgb_u8, tnext, counts + 2 * (l + 1), cap,            \
                      spawn ? 1 : 0, s->d_counters, counts_in, counts + OVERFLOW_SLOT, SortGrid{}, (const unsigned int*)nullptr, \
-                     (unsigned int*)nullptr, (unsigned int*)nullptr, (WfShadow*)nullptr, (unsigned int*)nullptr,     \
-                     ShadowPass{}, (long long)grid.x)
+                     (unsigned int*)nullptr, (unsigned int*)nullptr, Placement{nullptr, nullptr, 0}, (WfShadow*)nullptr, \
+                     (unsigned int*)nullptr, ShadowPass{}, (long long)grid.x)
       if (l == 0) {
         if (fast) NA_LAUNCH(true, true); else NA_LAUNCH(true, false);
       } else {

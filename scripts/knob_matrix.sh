@@ -13,8 +13,9 @@ run RT_SAH_SWEEP=100000000
 run RT_LBVH_TREELETS=0
 run RT_LBVH_BIG_TREELETS=0
 run RT_LBVH_TRAV=1
-run RT_SORT_RAYS=1
+run RT_SORT_RAYS=0
+run RT_SORT_RAYS=1 RT_SORT_MIN_LEVEL=2
 run RT_SORT_RAYS=1 RT_SORT_MIN_LEVEL=1
 run RT_SHADOW_PASS=1
-run RT_SHADOW_PASS=1 RT_SORT_RAYS=1 RT_SORT_MIN_LEVEL=1
+run RT_SHADOW_PASS=1 RT_SORT_RAYS=0
 run RT_SHADOW_PASS=1 RT_FRAME_SPLIT=3

@@ -18,6 +18,9 @@ F64_TOL = 1e-12
 
 # (environment, bvh_builder): 0 = host SAH tree, 1 = device-built tree
 KNOBS = [
+    ({"RT_SORT_RAYS": "0"}, 0),
+    ({"RT_SORT_RAYS": "0"}, 1),
+    ({"RT_SORT_RAYS": "1", "RT_SORT_MIN_LEVEL": "2"}, 0),
     ({"RT_SORT_RAYS": "1"}, 0),
     ({"RT_SORT_RAYS": "1", "RT_SORT_MIN_LEVEL": "1"}, 0),
     ({"RT_SORT_RAYS": "1", "RT_SORT_MIN_LEVEL": "1"}, 1),
@@ -62,9 +65,12 @@ def check(w, rt, want, pipeline):
     assert np.abs(f64 - of64).max() <= F64_TOL
     assert (st.rays_primary, st.rays_shadow, st.rays_reflect, st.rays_refract, st.depth0_skipped) == (
         cnt["primary"], cnt["shadow"], cnt["reflect"], cnt["refract"], cnt["depth0"])
-    # the frame again: issued from the remembered queue lengths, without read-backs
-    u8b, _, _ = w.render(pipeline=pipeline)
-    assert np.array_equal(u8b, ou8)
+    # the frame again, twice: issued from the remembered queue lengths, without read-backs, its rays
+    # placed in key order as they are emitted (the first render's sort passes left the places)
+    for _ in range(2):
+        u8b, f64b, stb = w.render(pipeline=pipeline, want_f64=True, want_stats=True)
+        assert np.array_equal(u8b, ou8) and np.array_equal(f64b, f64)
+        assert stb.rays() == st.rays() and stb.rays_shadow == st.rays_shadow
 
 
 @pytest.mark.parametrize("knob", KNOBS, ids=knob_id)
