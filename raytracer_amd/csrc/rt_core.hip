@@ -818,7 +818,11 @@ __device__ unsigned long long g_section_cycles[8];
 __device__ __forceinline__ long long wf_block_index() {
   const long long b = blockIdx.x;
   if (RT_XCD_CHUNK == 0) return b;
-  constexpr long long G = 8ll * (RT_XCD_CHUNK ? RT_XCD_CHUNK : 1);
+  if (RT_XCD_CHUNK < 0) {  // one run per XCD: an eighth of the launch each
+    const long long run = gridDim.x / 8;
+    return b < run * 8 ? (b % 8) * run + b / 8 : b;
+  }
+  constexpr long long G = 8ll * (RT_XCD_CHUNK > 0 ? RT_XCD_CHUNK : 1);
   const long long g = b / G;
   if ((g + 1) * G > (long long)gridDim.x) return b;
   const long long r = b - g * G;

@@ -752,14 +752,19 @@ __global__ void k_wide_level(const rtd::DNode* bn, const WideTask* front, int n_
   }
   const int here = w.above + (n > 0 ? n - 1 : 0);  // while one child is walked the others wait on the stack
   atomicMax(max_need, here);
+  // the inner children of one node take consecutive positions: siblings share cache lines, and
+  // the one that waits on the stack is fetched with the one that is walked first
+  int inner = 0;
+  for (int k = 0; k < n; k++) inner += code[k] >= 0;
+  int child = inner ? atomicAdd(n_wide, inner) : 0;
+  int slot = inner ? atomicAdd(n_next, inner) : 0;
   rtd::DNode4 N;
   for (int k = 0; k < 4; k++) {
     if (k < n) {
       for (int a = 0; a < 3; a++) N.q[3 * k + a] = q[k][a];
       if (code[k] >= 0) {
-        const int child = atomicAdd(n_wide, 1);
         N.c[k] = node_base + child;
-        next[atomicAdd(n_next, 1)] = WideTask{code[k], child, here};
+        next[slot++] = WideTask{code[k], child++, here};
       } else {
         N.c[k] = code[k];
       }
