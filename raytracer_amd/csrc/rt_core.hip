@@ -116,11 +116,13 @@ struct rt_scene {
     size_t wf_keys_cap[MAX_DEPTH + 1] = {};
     size_t wf_perm_cap[MAX_DEPTH + 1] = {};
     unsigned int* wf_hist = nullptr;  // SORT_BINS counters (zero between uses) + SORT_BINS cursors
-    unsigned int* wf_cursor[MAX_DEPTH + 1] = {};  // placed emission: SORT_BINS tickets per level, zeroed per frame
     size_t wf_task_cap[MAX_DEPTH + 1] = {};
     size_t wf_node_cap[MAX_DEPTH + 1] = {};
     size_t wf_live_cap[MAX_DEPTH + 1] = {};
-    unsigned int* wf_counts = nullptr;       // device: two counters per level, the overflow flag, then one shadow-queue length per level
+    // device: two counters per level, the overflow flag, one shadow-queue length per level; then, for
+    // placed emission, SORT_BINS tickets for each of the levels 1..MAX_DEPTH (one allocation, so that
+    // one fill at the start of a frame zeroes what the frame needs)
+    unsigned int* wf_counts = nullptr;
     unsigned int* wf_counts_host = nullptr;  // pinned
     // a frame issued on an estimate whose counters are on their way to wf_counts_host
     bool estimate_pending = false;
@@ -208,6 +210,8 @@ static constexpr size_t WF_MAX_PLANS = 64;
 constexpr int WF_OVERFLOW_SLOT = 2 * (MAX_DEPTH + 1);
 constexpr int WF_SHADOW_SLOT0 = 2 * (MAX_DEPTH + 2);
 constexpr int WF_N_COUNTS = WF_SHADOW_SLOT0 + MAX_DEPTH + 1;
+constexpr size_t WF_COUNTS_PAD = 64;  // u32 slots the counters take in their allocation (the tickets follow, 256-byte aligned)
+static_assert(WF_N_COUNTS <= (int)WF_COUNTS_PAD, "the counters outgrew their slots");
 // a plan that leaves the list takes its device tables with it (the scene's device must be current)
 static void drop_plan(rt_scene::WfPlan& p) {
   for (int l = 0; l <= MAX_DEPTH; l++) {
@@ -1215,7 +1219,6 @@ void rt_scene_destroy(rt_scene* s) {
         if (w->wf_shadow[l]) (void)hipFree(w->wf_shadow[l]);
         if (w->wf_keys[l]) (void)hipFree(w->wf_keys[l]);
         if (w->wf_perm[l]) (void)hipFree(w->wf_perm[l]);
-        if (w->wf_cursor[l]) (void)hipFree(w->wf_cursor[l]);
       }
       if (w->wf_counts) (void)hipFree(w->wf_counts);
       if (w->wf_hist) (void)hipFree(w->wf_hist);
@@ -1874,10 +1877,16 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
   w->last_use = ++s->wf_tick;
   w->estimate_pending = false;  // a new frame on this stream: an unasked verdict of an earlier one is void
   if (!w->wf_counts) {
-    HIP_TRY(hipMalloc(&w->wf_counts, WF_N_COUNTS * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(&w->wf_counts, (WF_COUNTS_PAD + (size_t)MAX_DEPTH * SORT_BINS) * sizeof(unsigned int)));
     HIP_TRY(hipHostMalloc(&w->wf_counts_host, WF_N_COUNTS * sizeof(unsigned int)));
   }
-  HIP_TRY(hipMemsetAsync(w->wf_counts, 0, WF_N_COUNTS * sizeof(unsigned int), st));
+  {
+    int placed_levels = 0;  // the tickets of levels 1..placed_levels are cleared with the counters
+    if (planned && s->sort_enabled)
+      for (int l = 1; l < depth; l++)
+        if (plan.place[l]) placed_levels = l;
+    HIP_TRY(hipMemsetAsync(w->wf_counts, 0, (WF_COUNTS_PAD + (size_t)placed_levels * SORT_BINS) * sizeof(unsigned int), st));
+  }
   long long n = ntiles * (RT_TILE * RT_TILE);
   long long n_front = n;     // level 0 has no queue
   unsigned int cap_in = 0;
@@ -1928,10 +1937,8 @@ static int render_wavefront(rt_scene* s, const DCamera& dc, const PixelMap& pm, 
     Placement place{nullptr, nullptr, ordered_in ? 1 : 0};
     const bool place_next = sort_next && planned && plan.place[l + 1] != nullptr;
     if (place_next) {
-      if (!w->wf_cursor[l + 1]) HIP_TRY(hipMalloc(&w->wf_cursor[l + 1], (size_t)SORT_BINS * sizeof(unsigned int)));
-      HIP_TRY(hipMemsetAsync(w->wf_cursor[l + 1], 0, (size_t)SORT_BINS * sizeof(unsigned int), st));
       place.off = plan.place[l + 1];
-      place.cur = w->wf_cursor[l + 1];
+      place.cur = w->wf_counts + WF_COUNTS_PAD + (size_t)l * SORT_BINS;  // cleared with the counters above
     }
     const unsigned int* perm_in = sorted_in ? static_cast<const unsigned int*>(w->wf_perm[l]) : nullptr;
     unsigned int* keys_next = (sort_next && !place_next) ? static_cast<unsigned int*>(w->wf_keys[l + 1]) : nullptr;
