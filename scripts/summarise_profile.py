@@ -8,16 +8,20 @@ import collections
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
 tag, out = sys.argv[1], sys.argv[2]
 root = f"gpurun_out/prof_{tag}"
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else int(json.load(open(f"{root}/stats_bench.json"))["frames_issued"])
-shutil.copy(glob.glob(f"{root}/stats/*/*kernel_stats.csv")[0], f"{out}_kernel_stats.csv")
+# gpurun merges every call's output into the same directories: of each pass, the newest file counts
+newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)
+shutil.copy(newest(f"{root}/stats/*/*kernel_stats.csv"), f"{out}_kernel_stats.csv")
 shutil.copy(f"{root}/stats_bench.json", f"{out}_bench.json")
 per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(f"{root}/pmc_*/*/*_counter_collection.csv"):
+for d in sorted(glob.glob(f"{root}/pmc_*/")):
+    f = newest(f"{d}*/*_counter_collection.csv")
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
         per_kernel[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
