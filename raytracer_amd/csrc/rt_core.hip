@@ -997,6 +997,13 @@ wf_level_body(const DScene& S, const DCamera& cam, const PixelMap& pm, const WfT
           surface.b += shadow ? dark.b : lit.b;
         }
       }
+#ifdef RT_SECTION_TIMES
+      {  // how much of the shadow walks runs in waves with few hits (slots 6, 7: under 16, under 32 of 64)
+        const int nh = __popcll(__ballot(hit));
+        if (nh < 16) section_sum_[6] += section_sum_[3];
+        if (nh < 32) section_sum_[7] += section_sum_[3];
+      }
+#endif
       if (hit) {
         nd.surface[0] = surface.r;
         nd.surface[1] = surface.g;

@@ -20,3 +20,4 @@ names = ["task load / ray generation", "closest-hit traversal",
 tot = sum(out[:6])
 for n, v in zip(names, out):
     print(f"{n:40s} {100.0 * v / tot:5.1f} %  {v / 1e6:10.1f} Mcycles")
+print(f"shadow traversal in waves with fewer than 16 / 32 hits of 64: {100.0 * out[6] / tot:.1f} % / {100.0 * out[7] / tot:.1f} % of all cycles")
