@@ -196,7 +196,11 @@ int rt_render(rt_scene*, const rt_camera*, int depth, int mode, int pipeline,
  * buffer of this shard: local tile k (global tile tile_first + k*tile_step) occupies
  * elements [k*RT_TILE*RT_TILE*3, (k+1)*RT_TILE*RT_TILE*3), pixels row-major inside the
  * tile; rt_shard_tiles() gives the tile count.  want_stats != 0 enables counters
- * (read them with rt_render_stats after synchronising the stream). */
+ * (read them with rt_render_stats after synchronising the stream).
+ * The wavefront pipeline remembers every frame it has rendered (camera, shard, depth, mode; a
+ * bounded list per scene): the first render of a frame reads its queue lengths back level by
+ * level (the call waits for the GPU then) and sorts its ray queues; the same frame afterwards is
+ * issued without a wait and writes its rays in sorted order as it goes.  Same bits either way. */
 #define RT_TILE 32
 int rt_render_device(rt_scene*, const rt_camera*, int depth, int mode, int pipeline,
                      int tile_first, int tile_step, double* d_rgb_f64, uint8_t* d_rgb_u8,
