@@ -129,7 +129,8 @@ typedef struct rt_camera {
 typedef struct rt_stats {
   uint64_t rays_primary, rays_shadow, rays_reflect, rays_refract;
   uint64_t depth0_skipped;
-  uint64_t pred_queries;  /* refraction-container predecessor queries (intersect.rs:188-222) */
+  uint64_t pred_queries;  /* refraction-container predecessor queries (intersect.rs:188-222); the wavefront
+                           * pipeline leaves them out at the deepest level, where n1 / n2 weigh black children */
   uint64_t nodes_visited; /* BVH nodes fetched */
   uint64_t tri_tests;     /* Möller–Trumbore evaluations (ttriangle.rs:9-34) */
   uint64_t prim_tests;    /* closed-form shape evaluations */

@@ -915,8 +915,17 @@ wf_level_body(const DScene& S, const DCamera& cam, const PixelMap& pm, const WfT
     // shading state is alive (and parked in scratch) while it walks.
     int mat_index = 0;
     if (hit) mat_index = h.prim >= 0 ? S.prims[h.prim].material : S.meshes[h.mesh].material;
-    const bool need = hit && needs_n1_n2(S.mats[mat_index]);
+    // n1 / n2 decide the refracted ray (world.rs:90-112) and weigh the two child colours
+    // (schlick, world.rs:151-165).  At the deepest level the children are color_at(ray, 0) —
+    // black whatever their rays — and black times any reflectance in [0, 1] is +0: the call's
+    // value is the same bits without them, so the walk that finds them is left out there.  (The
+    // kernels with counters keep it: total internal reflection decides whether a depth-0 child
+    // is counted.)
+    const bool need = hit && needs_n1_n2(S.mats[mat_index]) && (STATS || spawn != 0);
     double n1 = 1.0, n2 = 1.0;
+    // (... and leave its work out of their counts, which describe what the other kernels do)
+    Counters uncounted{};
+    if (STATS && spawn == 0) uncounted = cnt;
     {
       Key K{0.0, 0u, 0}, tb{0.0, 0u, 0};
       int tm = -1;
@@ -932,6 +941,7 @@ wf_level_body(const DScene& S, const DCamera& cam, const PixelMap& pm, const WfT
       RT_SECTION(4);
       if (need) containers_from<STATS>(S, ray, h, K, S.mats[mat_index].refractive_index, tf, tb, tm, n1, n2, cnt);
     }
+    if (STATS && spawn == 0) cnt = uncounted;
     Prep pr;
     pr.mat_index = 0;
     C3 surface = {0.0, 0.0, 0.0};
