@@ -1025,7 +1025,7 @@ wf_level_body(const DScene& S, const DCamera& cam, const PixelMap& pm, const WfT
       HitRec h;
       if (trace_closest<STATS>(S, ray, h, cnt, st)) {
         ShadeOut so;
-        shade_hit_local<STATS>(S, ray, h, so, cnt, st);
+        shade_hit_local<STATS>(S, ray, h, so, cnt, st, spawn != 0);
         has_children = emit_result<STATS>(so, so.surface, nd, i, next, next_count, next_cap, spawn, cnt, grid, next_keys, hist, place);
       }
     }

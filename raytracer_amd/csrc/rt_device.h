@@ -1785,9 +1785,14 @@ __device__ inline void finish_optics(const DMaterial& M, const Ray& ray, const P
 }
 
 // prepare_computations + the light loop of shade_hit + the child-ray set-up, in one lane.
+// children_traced: the call's reflected / refracted rays will be traced (remaining depth > 1).
+// When they will not — color_at(ray, 0) is black whatever the ray — n1 / n2 only weigh black
+// colours (black times a reflectance in [0, 1] is +0): the container query is left out, the
+// call's value is the same bits.  With counters it runs all the same (total internal
+// reflection decides whether a depth-0 child is counted) and stays out of the work counts.
 template <bool STATS>
 __device__ inline void shade_hit_local(const DScene& S, const Ray& ray, const HitRec& h,
-                                       ShadeOut& o, Counters& cnt, TravStack& st) {
+                                       ShadeOut& o, Counters& cnt, TravStack& st, bool children_traced = true) {
   if (STATS) cnt.shade_calls++;
   V3 point;
   Prep pr = prepare_hit(S, ray, h, &point);
@@ -1814,7 +1819,12 @@ __device__ inline void shade_hit_local(const DScene& S, const Ray& ray, const Hi
   }
   o.surface = surface;
   double n1 = 1.0, n2 = 1.0;
-  if (needs_n1_n2(M)) containers_n1_n2<STATS>(S, ray, h, M.refractive_index, n1, n2, cnt, st);
+  if (needs_n1_n2(M) && (STATS || children_traced)) {
+    Counters uncounted{};
+    if (STATS && !children_traced) uncounted = cnt;
+    containers_n1_n2<STATS>(S, ray, h, M.refractive_index, n1, n2, cnt, st);
+    if (STATS && !children_traced) cnt = uncounted;
+  }
   finish_optics(M, ray, pr, n1, n2, o);
 }
 
@@ -1857,7 +1867,7 @@ __device__ inline C3 color_at(const DScene& S, Ray ray, int depth, Counters& cnt
     bool returning = true;
     if (found && remaining > 0) {
       ShadeOut so;
-      shade_hit_local<STATS>(S, ray, h, so, cnt, st);
+      shade_hit_local<STATS>(S, ray, h, so, cnt, st, remaining > 1);
       {
         Frame& F = frames[level];
         F.surface = so.surface;
