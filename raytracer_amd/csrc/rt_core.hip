@@ -1181,6 +1181,16 @@ static int scratch_for_device(int device, unsigned char** out);
 
 // ---------------------------------------------------------------------------------------
 extern "C" {
+#ifdef RT_TRI_PLANE_STATS
+extern "C" int rt_debug_tri_plane(unsigned long long* out8, int reset) {
+  if (out8) HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(rtd::g_tri_plane), 8 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[8] = {};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_tri_plane), z, sizeof z));
+  }
+  return RT_OK;
+}
+#endif
 #ifdef RT_SECTION_TIMES
 int rt_debug_section_cycles(unsigned long long* out8, int reset) {
   if (out8) HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_section_cycles), 8 * sizeof(unsigned long long)));

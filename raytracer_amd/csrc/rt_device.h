@@ -106,6 +106,11 @@ __device__ __forceinline__ V3 normal_up_groups(const DScene& S, int g, V3 n) {
   return n;
 }
 
+#ifdef RT_TRI_PLANE_STATS
+// debug build: per query kind (closest, any): triangle tests, plane met behind the origin, plane met
+// beyond the interval, tests that hit
+__device__ unsigned long long g_tri_plane[8];
+#endif
 // ---------------------------------------------------------------------------------------
 // ttriangle.rs:9-34
 __device__ __forceinline__ bool moller_trumbore(const DTri& T, const Ray& r, double& t, double& u,
@@ -1197,6 +1202,19 @@ __device__ inline bool traverse_meshes_coop(const DScene& S, const Ray& ray, con
             const DTri T = decode_tri(raw);
             ok = moller_trumbore(T, r, wt, wu, wv) && (MODE == Q_PRED || wt > 0.0);
             worig = T.orig;
+#ifdef RT_TRI_PLANE_STATS
+            if (MODE != Q_PRED) {  // where does the ray meet the triangle's plane: behind, in the interval, beyond?
+              const V3 N = vcross(v3(T.e1[0], T.e1[1], T.e1[2]), v3(T.e2[0], T.e2[1], T.e2[2]));
+              const double a = vdot(N, vsub(r.o, v3(T.p1[0], T.p1[1], T.p1[2]))), b = vdot(N, r.d);
+              const double tp = -a / b;
+              const double ohi = __shfl(q.hi, o, 64);
+              const int base_ = MODE == Q_CLOSEST ? 0 : 4;
+              atomicAdd(&g_tri_plane[base_ + 0], 1ull);
+              if (!(tp > 0.0)) atomicAdd(&g_tri_plane[base_ + 1], 1ull);
+              else if (tp > ohi) atomicAdd(&g_tri_plane[base_ + 2], 1ull);
+              if (ok) atomicAdd(&g_tri_plane[base_ + 3], 1ull);
+            }
+#endif
           }
         }
         unsigned long long mask = __ballot(ok);
