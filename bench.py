@@ -346,13 +346,19 @@ def main():
         return dt, max(ev_start.elapsed_time(e) for e in ev_end) / steps
 
     elapsed, kernel_ms = timed(args.steps)
-    # the same loop sustained for at least a second (the K timed steps above last ~50 ms)
+    if n > 1:
+        t = all_reduce(torch.tensor([elapsed, kernel_ms, frame_latency_ms], dtype=torch.float64, device=dev),
+                       dist.ReduceOp.MAX)
+        elapsed, kernel_ms, frame_latency_ms = t.tolist()
+    # the same loop sustained for some seconds (the K timed steps above last ~50 ms).  Its length comes
+    # from the time just measured — the maximum over the ranks, so that every rank issues the same
+    # number of frames (each frame is one exchange: ranks that disagreed would wait for one another
+    # for ever)
     sustained_steps = max(args.steps, int(math.ceil(args.sustain_s / max(elapsed / args.steps, 1e-6))))
     sustained_s, sustained_kernel_ms = timed(sustained_steps) if args.sustain_s > 0 else (elapsed, kernel_ms)
     if n > 1:
-        t = all_reduce(torch.tensor([elapsed, kernel_ms, frame_latency_ms, sustained_s], dtype=torch.float64, device=dev),
-                       dist.ReduceOp.MAX)
-        elapsed, kernel_ms, frame_latency_ms, sustained_s = t.tolist()
+        t = all_reduce(torch.tensor([sustained_s, sustained_kernel_ms], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
+        sustained_s, sustained_kernel_ms = t.tolist()
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps

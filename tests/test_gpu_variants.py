@@ -282,10 +282,14 @@ def test_two_rank_bench_rehearsal_gives_the_one_gpu_frame(rt):
     env["RT_BENCH_REHEARSAL_ONE_GPU"] = "1"
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port),
-                          os.path.join(repo, "bench.py"), "--gpus", "2"] + common,
+                          os.path.join(repo, "bench.py"), "--gpus", "2"] +
+                         # with the sustained loop the driver's default flags run: its length must be the
+                         # same on every rank (one exchange per frame)
+                         [a if a != "0" else "0.3" for a in common],
                          capture_output=True, text=True, timeout=300, env=env, cwd=repo)
     assert two.returncode == 0, two.stderr[-2000:]
     line2 = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert line2["n_gpus"] == 2 and line1["n_gpus"] == 1
     assert line2["config"]["frame_crc32"] == line1["config"]["frame_crc32"]
     assert line2["config"]["rays_per_frame"] == line1["config"]["rays_per_frame"]
+    assert line2["sustained"]["steps"] >= 2 and line2["sustained"]["seconds"] > 0
