@@ -636,29 +636,40 @@ struct Placement {
   unsigned int* cur;        // next level: tickets per key, zero when the frame starts
   int ordered_in;           // this level's queue is already in key order: task i is call i
 };
-// The place of one emitted task.  Lanes that share the first lane's key take their tickets with
-// one atomic (a wave of floor reflections has one or two keys); after a few such groups the
-// rest take theirs one by one.
-__device__ __forceinline__ unsigned int place_position(const Placement& P, unsigned int key) {
-  unsigned long long todo = __ballot(1);
-  const int lane = (int)__lane_id();
-  unsigned int pos = 0;
-  bool placed = false;
-  for (int turn = 0; turn < 4 && todo; turn++) {  // uniform over the lanes that came in
-    const int leader = __ffsll((long long)todo) - 1;
-    const unsigned int k = (unsigned int)__builtin_amdgcn_readlane((int)key, leader);
-    const unsigned long long same = __ballot(key == k);
-    unsigned int base = 0;
-    if (lane == leader) base = atomicAdd(&P.cur[k], (unsigned int)__popcll(same));
-    base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
-    if (key == k) {
-      pos = P.off[k] + base + (unsigned int)__popcll(same & ((1ull << lane) - 1ull));
-      placed = true;
-    }
+// The lanes among `want` that share this lane's key (0 for a lane outside `want`).  Called by all
+// the lanes of a converged region.
+__device__ __forceinline__ unsigned long long lanes_with_my_key(bool want, unsigned int key) {
+  unsigned long long todo = __ballot(want);
+  unsigned long long mine = 0ull;
+  while (todo) {  // uniform
+    const int first = __ffsll((long long)todo) - 1;
+    const unsigned int k = (unsigned int)__builtin_amdgcn_readlane((int)key, first);
+    const unsigned long long same = __ballot(want && key == k);
+    if (want && key == k) mine = same;
     todo &= ~same;
   }
-  if (!placed) pos = P.off[key] + atomicAdd(&P.cur[key], 1u);
-  return pos;
+  return mine;
+}
+// The places of a call's two child rays.  The lanes that share a key take their tickets with one
+// atomic of the group's first lane; the groups are found with ballots and lane reads alone, so
+// all of them — of the reflected and of the refracted rays — issue their atomics before any is
+// waited for: one memory round trip per call on the wave's dependent chain (a round trip per
+// group, as first written, cost the pawn frame 2 %).
+__device__ __forceinline__ void place_two(const Placement& P, bool want_a, unsigned int key_a, bool want_b,
+                                          unsigned int key_b, unsigned int& pos_a, unsigned int& pos_b) {
+  const int lane = (int)__lane_id();
+  const unsigned long long mine_a = lanes_with_my_key(want_a, key_a), mine_b = lanes_with_my_key(want_b, key_b);
+  const int lead_a = want_a ? __ffsll((long long)mine_a) - 1 : lane, lead_b = want_b ? __ffsll((long long)mine_b) - 1 : lane;
+  unsigned int start_a = 0, start_b = 0, base_a = 0, base_b = 0;
+  if (want_a) start_a = P.off[key_a];
+  if (want_b) start_b = P.off[key_b];
+  if (want_a && lane == lead_a) base_a = atomicAdd(&P.cur[key_a], (unsigned int)__popcll(mine_a));
+  if (want_b && lane == lead_b) base_b = atomicAdd(&P.cur[key_b], (unsigned int)__popcll(mine_b));
+  base_a = (unsigned int)__shfl((int)base_a, lead_a, 64);
+  base_b = (unsigned int)__shfl((int)base_b, lead_b, 64);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  pos_a = start_a + base_a + (unsigned int)__popcll(mine_a & below);
+  pos_b = start_b + base_b + (unsigned int)__popcll(mine_b & below);
 }
 // exclusive prefix sum of the histogram into `cursor` (one block); leaves the histogram zeroed
 __global__ void __launch_bounds__(1024) k_wf_sort_scan(unsigned int* hist, unsigned int* cursor) {
@@ -735,10 +746,14 @@ __device__ __forceinline__ bool emit_result(const ShadeOut& so, const C3& surfac
     nd.reflected[k] = 0.0;
     nd.refracted[k] = 0.0;
   }
+  // (placed: the queue holds exactly the tasks of the frame that left the plan behind)
+  unsigned int placed_reflect = 0, placed_refract = 0;
+  if (place.off && spawn)
+    place_two(place, so.do_reflect, so.do_reflect ? sort_key(grid, so.reflect_ray, 1u) : 0u, so.do_refract,
+              so.do_refract ? sort_key(grid, so.refract_ray, 0u) : 0u, placed_reflect, placed_refract);
   if (so.do_reflect) {
     if (spawn) {
-      // (placed: the queue holds exactly the tasks of the frame that left the plan behind)
-      const unsigned int idx = place.off ? place_position(place, sort_key(grid, so.reflect_ray, 1u)) : atomicAdd(next_count, 1u);
+      const unsigned int idx = place.off ? placed_reflect : atomicAdd(next_count, 1u);
       if (idx < next_cap) {
         WfTask& T = next[idx];
         T.o[0] = so.reflect_ray.o.x;
@@ -762,7 +777,7 @@ __device__ __forceinline__ bool emit_result(const ShadeOut& so, const C3& surfac
   }
   if (so.do_refract) {
     if (spawn) {
-      const unsigned int idx = place.off ? place_position(place, sort_key(grid, so.refract_ray, 0u)) : atomicAdd(next_count + 1, 1u);
+      const unsigned int idx = place.off ? placed_refract : atomicAdd(next_count + 1, 1u);
       if (idx < next_cap) {
         WfTask& T = next[place.off ? idx : next_cap - 1 - idx];
         T.o[0] = so.refract_ray.o.x;
